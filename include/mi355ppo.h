@@ -1,0 +1,124 @@
+/* libmi355ppo -- C ABI of the MI355X-native PPO hot path.
+ *
+ * The reference (tbuckworth/train-procgen-pytorch) has no FFI for this path: its boundary is the
+ * duck-typed Python API of agents/ppo.py (PPO), common/storage.py (Storage) and common/policy.py
+ * (CategoricalPolicy) -- SURVEY.md section 8(b).  This header is the C boundary a binding for that API
+ * sits on (ours: train-procgen-pytorch_amd/mi355/engine.py via ctypes).  Each entry
+ * point names the reference interface it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative code on error (mi_last_error()
+ * gives the text).  The caller owns all host buffers; the context owns all device memory.  One
+ * context per GPU per process.  All work is issued on the context's HIP stream; functions that
+ * return data to host buffers synchronise that stream before returning, the others are asynchronous
+ * (use mi_sync).  No torch types appear here.
+ */
+#ifndef MI355PPO_H
+#define MI355PPO_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_ctx mi_ctx;
+
+enum { MI_ARCH_IMPALA = 0, MI_ARCH_MLP = 1 };
+
+typedef struct mi_config {
+    int32_t arch;          /* MI_ARCH_IMPALA: common/model.py:167-209 ; MI_ARCH_MLP: common/model.py:954-980 */
+    int32_t n_steps;       /* T  (Storage num_steps, common/storage.py:9) */
+    int32_t n_envs;        /* E  local envs on this rank (Storage num_envs) */
+    int32_t n_actions;     /* A  (CategoricalPolicy action_size, common/policy.py:22) ; 1 <= A <= 16 */
+    int32_t obs_dim;       /* MLP only: observation vector length (IMPALA is fixed 64x64x3 uint8 NHWC) */
+    int32_t mlp_depth;     /* MLP only: MLPModel depth (>= 2) */
+    int32_t mlp_width;     /* MLP only: MLPModel mid_weight */
+    int32_t out_dim;       /* embedder.output_dim: 256 for IMPALA, latent_size for MLP */
+    int32_t max_batch;     /* largest number of samples one mi_minibatch / mi_forward call may carry */
+    int32_t device;        /* HIP device ordinal */
+    int32_t reserved[6];
+    void*   stream;        /* hipStream_t to issue on, or NULL for a stream owned by the context */
+} mi_config;
+
+/* PPO.__init__ hyper-parameters used inside the minibatch step (agents/ppo.py:10-70) */
+typedef struct mi_hparams {
+    float eps_clip, value_coef, entropy_coef, x_entropy_coef, entropy_multiplier, fs_coef;
+} mi_hparams;
+
+const char* mi_last_error(void);
+int mi_create(const mi_config* cfg, mi_ctx** out);
+int mi_destroy(mi_ctx* ctx);
+int mi_sync(mi_ctx* ctx);
+/* pinned (page-locked) host memory for the rollout staging buffers: mi_put_obs / mi_put_step from such a
+ * buffer is a true asynchronous DMA (the reference copies pageable numpy arrays, agents/ppo.py:74-76) */
+void* mi_host_alloc(size_t bytes);
+void  mi_host_free(void* p);
+
+/* ---- parameters / optimiser state: flat fp32 vectors in the REFERENCE's policy.parameters() order and
+ *      tensor layouts (policy.state_dict(), train.py:257-263 / agents/ppo.py:271-276).  The library
+ *      converts to / from its device layouts (NHWC filter banks, NHWC-flatten fc columns). */
+int64_t mi_param_count(mi_ctx* ctx);
+int mi_set_params(mi_ctx* ctx, const float* flat, int64_t n);
+int mi_get_params(mi_ctx* ctx, float* flat, int64_t n);
+int mi_get_grads(mi_ctx* ctx, float* flat, int64_t n);                     /* accumulated, un-clipped */
+int mi_set_adam_state(mi_ctx* ctx, const float* exp_avg, const float* exp_avg_sq, int64_t n);
+int mi_get_adam_state(mi_ctx* ctx, float* exp_avg, float* exp_avg_sq, int64_t n);
+
+/* ---- rollout storage (Storage.store / store_last, common/storage.py:39-54).  t in [0, T]. */
+int mi_put_obs(mi_ctx* ctx, int32_t t, const void* obs, size_t bytes);     /* E frames uint8 NHWC, or E x obs_dim fp32 */
+int mi_put_step(mi_ctx* ctx, int32_t t, const float* rew, const float* done);            /* rew/done (E,) */
+/* teacher forcing / compat path: overwrite what the policy step stored.  Any pointer may be NULL. */
+int mi_put_policy_outputs(mi_ctx* ctx, int32_t t, const int32_t* act, const float* logp, const float* value);
+enum { MI_F_REW = 0, MI_F_DONE, MI_F_VALUE, MI_F_LOGP, MI_F_ADV, MI_F_RET, MI_F_ACT };
+int mi_read_field(mi_ctx* ctx, int32_t field, float* out, int64_t n);      /* (T,E) fp32; VALUE is (T+1,E); ACT as float */
+int mi_write_field(mi_ctx* ctx, int32_t field, const float* in, int64_t n);
+
+/* ---- PPO.predict on the stored observation of step t (agents/ppo.py:72-81): forward, sample, log_prob.
+ *      t < T: writes act/logp/value[t]; t == T: writes value[T] only (store_last).  u: optional E uniforms
+ *      in [0,1) for the inverse-CDF sampler (NULL -> Philox4x32-10 keyed by seed and t*E+e).
+ *      Host outputs may be NULL (then the call does not synchronise). */
+int mi_policy_step(mi_ctx* ctx, int32_t t, uint64_t seed, const float* u,
+                   int64_t* act_out, float* logp_out, float* value_out);
+
+/* ---- stateless forward on caller data (policy(obs, hx, masks) / hidden_to_output, common/policy.py:61-87).
+ *      obs: n frames uint8 NHWC or n x obs_dim fp32.  logp_all: n x A normalised log-probs
+ *      (Categorical.logits); value: n; feat: n x out_dim.  Outputs may be NULL. */
+int mi_forward(mi_ctx* ctx, const void* obs, int32_t n, float* logp_all, float* value, float* feat);
+
+/* ---- Storage.compute_estimates (common/storage.py:56-79) on the device-resident rollout */
+int mi_compute_estimates(mi_ctx* ctx, float gamma, float lmbda, int32_t use_gae, int32_t normalize_adv);
+/* multi-rank advantage normalisation: stats = {count, mean, M2} (fp64) of the local un-normalised advantages */
+int mi_adv_stats(mi_ctx* ctx, double stats3[3]);
+int mi_adv_apply(mi_ctx* ctx, const double stats3[3]);
+
+/* ---- one minibatch of PPO.optimize (agents/ppo.py:119-170): gather by flat index i = t*E + e (local),
+ *      forward, loss, backward; gradients ACCUMULATE into the flat gradient buffer (the reference's
+ *      unscaled accumulation).  n_global = size of the global minibatch the means are taken over
+ *      (= n_idx on one GPU).  Appends one 8-float record to the device loss log:
+ *      {pi_loss, value_loss, entropy, x_ent, total, feature_sparsity, marginal_entropy, 0}. */
+int mi_minibatch(mi_ctx* ctx, const int64_t* idx, int32_t n_idx, int32_t n_global, const mi_hparams* hp);
+/* clip_grad_norm_ + Adam.step + zero_grad (agents/ppo.py:174-176); adam_step = 1-based step count */
+int mi_optimizer_step(mi_ctx* ctx, float lr, float max_grad_norm, int32_t adam_step, float* grad_norm_out);
+int mi_loss_log_read(mi_ctx* ctx, float* out, int32_t max_records, int32_t* n_records, int32_t reset);
+
+/* ---- raw device pointers for collectives issued by the host side (RCCL through torch.distributed) */
+enum { MI_PTR_GRADS = 0, MI_PTR_LOSS_STATS = 1, MI_PTR_PARAMS = 2 };
+int mi_device_ptr(mi_ctx* ctx, int32_t which, void** ptr, int64_t* n_floats);
+/* two-phase loss finalisation for multi-rank runs (phase 2 after the cross-rank sum of the stats) */
+int mi_set_multirank(mi_ctx* ctx, int32_t enabled);
+int mi_minibatch_finish(mi_ctx* ctx);      /* multirank only: phase 2 + backward after the stats all-reduce */
+
+/* ---- op-level entry points for parity tests (host buffers in, host buffers out; NHWC fp32) */
+int mi_op_conv3x3(mi_ctx* ctx, int32_t mode /*0 fwd,1 dgrad,2 wgrad*/, int32_t cin, int32_t cout, int32_t hw, int32_t n,
+                  const void* in, int32_t in_is_u8, int32_t relu_in, const float* w_ref /*[cout][cin][3][3]*/,
+                  const float* bias, const float* res, const float* mask, const float* dout,
+                  float* out /*fwd/dgrad: activations; wgrad: [cout][cin][3][3]*/, float* dbias_out);
+int mi_op_maxpool(mi_ctx* ctx, int32_t mode /*0 fwd,1 bwd*/, int32_t n, int32_t hw, int32_t c,
+                  const float* in, const float* dout, float* out);
+int mi_op_gemm(mi_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak,
+               const float* B, int64_t sbk, int64_t sbn, float* C);
+int mi_selftest_mfma(mi_ctx* ctx, float* max_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

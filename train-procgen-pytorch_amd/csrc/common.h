@@ -1,0 +1,112 @@
+// Shared declarations for the MI355X PPO hot-path library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MI_WAVE 64
+
+// ---------------------------------------------------------------- conv3x3 (NHWC, stride 1, pad 1)
+// One descriptor serves forward and data-gradient launches (dgrad = forward form over dOut with
+// the tap-flipped, channel-transposed weight view; see conv.hip).
+struct ConvArgs {
+    const void*    in;        // fp32 NHWC [n][HW][HW][CIN]  (or uint8 frames NHWC when the shape is the u8 one)
+    const int32_t* idx;       // u8 input only: sample s reads frame idx[s] (minibatch gather); null -> in_base + s
+    long long      in_base;   // u8 input only: first frame when idx == null (rollout step t -> t*E)
+    const float*   w;         // device weight layout [CO][9][CI] (tap = ky*3+kx), CO/CI of the FORWARD conv
+    const float*   bias;      // [COUT] or null
+    const float*   res;       // optional residual, same shape as out: out += res
+    const float*   mask;      // optional ReLU mask source, same shape as out: out *= (mask > 0)
+    float*         out;       // fp32 NHWC [n][HW][HW][COUT]
+    const float*   lut;       // 256-entry u8 -> fp32 table (k/255 correctly rounded)
+    int            n;         // images
+    int            relu_in;   // apply max(x,0) while staging the input tile
+};
+
+struct WgradArgs {
+    const void*    in;        // forward input of the conv (fp32 NHWC or u8 frames)
+    const int32_t* idx;
+    long long      in_base;
+    const float*   dout;      // fp32 NHWC [n][HW][HW][COUT]
+    float*         partial;   // [gridDim.x][COUT*9*CIN + COUT] per-workgroup slabs (weights then bias)
+    const float*   lut;
+    int            n;
+    int            relu_in;
+};
+
+enum ConvShape {              // (CIN, COUT, HW) of the FORWARD conv
+    CS_3_16_64 = 0,           // block1.conv   (uint8 frames in)
+    CS_16_16_32,              // block1.res*.conv*
+    CS_16_32_32,              // block2.conv
+    CS_32_32_16,              // block2.res*.conv*, block3.conv
+    CS_32_32_8,               // block3.res*.conv*
+    CS_COUNT
+};
+
+// launchers (conv.hip).  grid_blocks <= 0 -> library default.
+void launch_conv_fwd(ConvShape s, const ConvArgs& a, hipStream_t st);
+void launch_conv_dgrad(ConvShape s, const ConvArgs& a, hipStream_t st);   // a.in = dOut, a.out = dIn
+int  wgrad_grid(ConvShape s, int n);                                       // workgroups a wgrad launch will use
+void launch_conv_wgrad(ConvShape s, const WgradArgs& a, hipStream_t st);
+void conv_shape_dims(ConvShape s, int* cin, int* cout, int* hw);
+
+// ---------------------------------------------------------------- generic MFMA GEMM (linear layers)
+// C[M][N] (op)= sum_k A(m,k) * B(k,n);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long long sam, sak, sbk, sbn, ldc;
+    const float* bias;     // per-n bias or null
+    const float* mask;     // C *= (mask[m*ldc+n] > 0) or null
+    int relu_a, relu_b;    // max(x,0) on operand load
+    int relu_out;          // max(c,0) in the epilogue (after bias)
+    int accumulate;        // C += result
+};
+void launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// ---------------------------------------------------------------- small kernels (misc.hip)
+void launch_maxpool_fwd(const float* in, float* out, uint8_t* arg, int n, int hw, int c, hipStream_t st);
+void launch_maxpool_bwd(const float* dout, const uint8_t* arg, float* din, int n, int hw, int c, hipStream_t st);
+void launch_reduce_slabs(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b,
+                         hipStream_t st);
+void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, hipStream_t st);
+void launch_gather_rows(const float* src, const int32_t* idx, long long base, float* dst, int n, int d, hipStream_t st);
+
+struct LossHP { float eps_clip, value_coef, entropy_coef, x_entropy_coef, entropy_mult, fs_coef; };
+// per-sample scalars are gathered through idx (flat index t*E+e) from the (T,E) rollout arrays
+struct LossArgs {
+    const float* hout;        // [n][A+1] logits then value
+    const int32_t* idx;       // [n]
+    const int32_t* act; const float* old_logp; const float* old_value; const float* ret; const float* adv;
+    float* dY;                // [n][A+1] gradient wrt logits/value (loss_bwd)
+    float* partial;           // [nblk][8+A]
+    float* stats;             // [16+A] finalised: 0 pi_loss 1 value_loss 2 entropy 3 x_ent 4 total 5 fs 6 marg 8.. q[A]
+    int n, A;
+    float inv_n_global;       // 1 / (global minibatch size)
+    LossHP hp;
+};
+int  loss_blocks(int n);
+void launch_loss_fwd(const LossArgs& a, hipStream_t st);
+// phase bit 0: block partials -> this rank's share of the global means; bit 1: derived terms + log record
+void launch_loss_finalize(const LossArgs& a, int nblk, int phase, const float* fs_ptr, float* log_slot, hipStream_t st);
+void launch_logp_all(const float* hout, int n, int A, float* lp_out, float* value_out, hipStream_t st);
+void gemm_set_workspace(float* ws, size_t floats);
+void colsum_set_workspace(float* ws);   // >= 64 * max_N floats
+void launch_loss_bwd(const LossArgs& a, hipStream_t st);
+void launch_fs_metric(const float* flat_pre, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st);
+
+void launch_gae(const float* rew, const float* done, const float* value, float* adv, float* ret, int T, int E,
+                float gamma, float lmbda, int use_gae, hipStream_t st);
+void launch_advnorm_stats(const float* adv, int n, double* stats3, hipStream_t st);   // stats3 = {count, mean, M2}
+void launch_advnorm_apply(float* adv, int n, const double* stats3, hipStream_t st);
+
+void launch_sample(const float* hout, int n, int A, const float* u, unsigned long long seed, unsigned long long ctr,
+                   int32_t* act, float* logp, float* value, hipStream_t st);
+
+void launch_sumsq(const float* g, long long n, double* out, hipStream_t st);          // out[0] = sum g^2 (deterministic)
+void launch_adam(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr,
+                 float beta1, float beta2, float eps, float step_size_scale, float bc2_sqrt, float* gnorm_out,
+                 hipStream_t st);
+void launch_fill(float* p, long long n, float v, hipStream_t st);

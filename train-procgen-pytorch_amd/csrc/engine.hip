@@ -1,0 +1,798 @@
+// Context, network program and the C ABI (include/mi355ppo.h) of the MI355X PPO hot path.
+//
+// Device-resident state per context (one per GPU):
+//   rollout ring   frames uint8 NHWC [(T+1)][E][64][64][3]  (or fp32 [(T+1)][E][obs_dim] for the MLP)
+//                  rew/done/logp/adv/ret fp32 [T][E], act int32 [T][E], value fp32 [T+1][E]
+//   parameters     ONE flat fp32 buffer (+ grad, exp_avg, exp_avg_sq of the same shape): filter banks
+//                  as [co][tap][ci], fc columns in NHWC-flatten order, heads as one (A+1) x H matrix
+//   activations    NHWC fp32, every tensor the backward pass needs, sized for max_batch samples
+// The reference keeps all of this on the host in fp32 and re-uploads a gathered minibatch for every
+// update (common/storage.py:112-128); here the minibatch gather is an index read inside the first conv.
+#include "common.h"
+#include "../../include/mi355ppo.h"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+const char* mi_last_error(void) { return g_err.c_str(); }
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPC(x)                                                                                          \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(-2, std::string(#x) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+    } while (0)
+#define ARG(c, msg) do { if (!(c)) return fail(-1, std::string("invalid argument: ") + msg); } while (0)
+
+enum TKind { K_PLAIN = 0, K_CONVW, K_FCW };
+struct TensorDesc {
+    std::string name;
+    int64_t ref_off, dev_off, n;
+    int kind, co, ci;
+};
+
+struct ConvLayer { ConvShape shape; int64_t w_off, b_off; int cin, cout, hw; };
+struct Block { float *C, *P0, *A1, *P1, *A2, *P2; uint8_t* PI; int cin, cout, hin; };
+struct Linear { int64_t w_off, b_off; int in, out; };
+
+struct mi_ctx {
+    mi_config cfg;
+    hipStream_t stream;
+    bool own_stream;
+    int T, E, A, H, NB;
+    int64_t n_params;
+    std::vector<TensorDesc> tensors;
+    float *params, *grads, *adam_m, *adam_v;
+    // rollout
+    uint8_t* frames;      // impala
+    float* obsf;          // mlp
+    size_t obs_bytes_per_env;
+    float *rew, *done, *logp, *adv, *ret, *value;
+    int32_t* act;
+    double* adv_stats;
+    // network
+    std::vector<ConvLayer> convs;
+    Block blk[3];
+    Linear fc;            // impala fc 2048->256
+    std::vector<Linear> mlp;
+    std::vector<float*> mlp_act;   // X0 (input), h1..hL
+    int64_t wh_off, bh_off;        // heads: (A+1) x H weights, (A+1) bias (device order)
+    float *feat, *hout, *dY, *dfeat, *GC, *GP[3];
+    float* slabs; size_t slab_floats;
+    float *gemm_ws, *col_ws, *fs_scratch, *fs_val;
+    float* lut;
+    uint8_t* stage_frames; float* stage_obs;
+    int32_t* d_idx;
+    float *loss_partial, *loss_stats, *loss_log; int log_count, log_cap;
+    double* sumsq; float* gnorm;
+    float* d_u; float* d_lp;
+    // pinned host staging
+    int32_t* h_idx; float* h_f; int32_t* h_i; size_t h_f_floats;
+    int multirank;
+    LossArgs pending; int pending_n;
+};
+
+// ------------------------------------------------------------------------------------------ layout tables
+static void add_tensor(mi_ctx* c, const std::string& name, int64_t n, int kind, int co, int ci, int64_t& ref, int64_t dev) {
+    TensorDesc t{name, ref, dev, n, kind, co, ci};
+    c->tensors.push_back(t);
+    ref += n;
+}
+
+static void build_impala_layout(mi_ctx* c) {
+    // reference order = policy.parameters(): embedder.block{1,2,3}.{conv,res1.conv1,res1.conv2,res2.conv1,res2.conv2}.{weight,bias},
+    // embedder.fc.{weight,bias}, fc_policy.{weight,bias}, fc_value.{weight,bias}   
+    const int chan[4] = {3, 16, 32, 32};
+    const ConvShape first[3] = {CS_3_16_64, CS_16_32_32, CS_32_32_16};
+    const ConvShape resid[3] = {CS_16_16_32, CS_32_32_16, CS_32_32_8};
+    const char* sub[5] = {"conv", "res1.conv1", "res1.conv2", "res2.conv1", "res2.conv2"};
+    int64_t ref = 0;
+    for (int b = 0; b < 3; ++b)
+        for (int k = 0; k < 5; ++k) {
+            const int ci = (k == 0) ? chan[b] : chan[b + 1], co = chan[b + 1];
+            const std::string base = "embedder.block" + std::to_string(b + 1) + "." + sub[k];
+            ConvLayer L;
+            L.shape = (k == 0) ? first[b] : resid[b];
+            conv_shape_dims(L.shape, &L.cin, &L.cout, &L.hw);
+            L.w_off = ref;
+            add_tensor(c, base + ".weight", (int64_t)co * ci * 9, K_CONVW, co, ci, ref, ref);
+            L.b_off = ref;
+            add_tensor(c, base + ".bias", co, K_PLAIN, 0, 0, ref, ref);
+            c->convs.push_back(L);
+        }
+    c->fc.in = 2048; c->fc.out = c->H;
+    c->fc.w_off = ref; add_tensor(c, "embedder.fc.weight", (int64_t)c->H * 2048, K_FCW, c->H, 2048, ref, ref);
+    c->fc.b_off = ref; add_tensor(c, "embedder.fc.bias", c->H, K_PLAIN, 0, 0, ref, ref);
+    const int64_t h0 = ref;
+    c->wh_off = h0; c->bh_off = h0 + (int64_t)(c->A + 1) * c->H;
+    add_tensor(c, "fc_policy.weight", (int64_t)c->A * c->H, K_PLAIN, 0, 0, ref, c->wh_off);
+    add_tensor(c, "fc_policy.bias", c->A, K_PLAIN, 0, 0, ref, c->bh_off);
+    add_tensor(c, "fc_value.weight", c->H, K_PLAIN, 0, 0, ref, c->wh_off + (int64_t)c->A * c->H);
+    add_tensor(c, "fc_value.bias", 1, K_PLAIN, 0, 0, ref, c->bh_off + c->A);
+    c->n_params = ref;
+}
+
+static void build_mlp_layout(mi_ctx* c) {
+    // MLPModel (common/model.py:954-980): Linear(in,w) ReLU [Linear(w,w) ReLU]*(depth-2) Linear(w,latent)
+    const int d = c->cfg.mlp_depth, w = c->cfg.mlp_width;
+    int64_t ref = 0;
+    auto lin = [&](const std::string& nm, int in, int out) {
+        Linear L; L.in = in; L.out = out;
+        L.w_off = ref; add_tensor(c, nm + ".weight", (int64_t)in * out, K_PLAIN, 0, 0, ref, ref);
+        L.b_off = ref; add_tensor(c, nm + ".bias", out, K_PLAIN, 0, 0, ref, ref);
+        c->mlp.push_back(L);
+    };
+    lin("embedder.model.0", c->cfg.obs_dim, w);
+    for (int k = 0; k < d - 2; ++k) lin("embedder.model.2." + std::to_string(2 * k), w, w);
+    lin("embedder.model.3", w, c->H);
+    const int64_t h0 = ref;
+    c->wh_off = h0; c->bh_off = h0 + (int64_t)(c->A + 1) * c->H;
+    add_tensor(c, "fc_policy.weight", (int64_t)c->A * c->H, K_PLAIN, 0, 0, ref, c->wh_off);
+    add_tensor(c, "fc_policy.bias", c->A, K_PLAIN, 0, 0, ref, c->bh_off);
+    add_tensor(c, "fc_value.weight", c->H, K_PLAIN, 0, 0, ref, c->wh_off + (int64_t)c->A * c->H);
+    add_tensor(c, "fc_value.bias", 1, K_PLAIN, 0, 0, ref, c->bh_off + c->A);
+    c->n_params = ref;
+}
+
+// reference layout <-> device layout for one tensor (host side)
+static void to_device_layout(const TensorDesc& t, const float* ref, float* dev) {
+    if (t.kind == K_CONVW) {            // [co][ci][3][3] -> [co][tap][ci]
+        for (int co = 0; co < t.co; ++co)
+            for (int ci = 0; ci < t.ci; ++ci)
+                for (int tap = 0; tap < 9; ++tap) dev[((int64_t)co * 9 + tap) * t.ci + ci] = ref[((int64_t)co * t.ci + ci) * 9 + tap];
+    } else if (t.kind == K_FCW) {       // columns c*64 + h*8 + w (NCHW flatten, model.py:54-56) -> (h*8+w)*32 + c
+        for (int o = 0; o < t.co; ++o)
+            for (int ch = 0; ch < 32; ++ch)
+                for (int p = 0; p < 64; ++p) dev[(int64_t)o * 2048 + p * 32 + ch] = ref[(int64_t)o * 2048 + ch * 64 + p];
+    } else memcpy(dev, ref, t.n * sizeof(float));
+}
+static void to_ref_layout(const TensorDesc& t, const float* dev, float* ref) {
+    if (t.kind == K_CONVW) {
+        for (int co = 0; co < t.co; ++co)
+            for (int ci = 0; ci < t.ci; ++ci)
+                for (int tap = 0; tap < 9; ++tap) ref[((int64_t)co * t.ci + ci) * 9 + tap] = dev[((int64_t)co * 9 + tap) * t.ci + ci];
+    } else if (t.kind == K_FCW) {
+        for (int o = 0; o < t.co; ++o)
+            for (int ch = 0; ch < 32; ++ch)
+                for (int p = 0; p < 64; ++p) ref[(int64_t)o * 2048 + ch * 64 + p] = dev[(int64_t)o * 2048 + p * 32 + ch];
+    } else memcpy(ref, dev, t.n * sizeof(float));
+}
+
+static int upload_flat(mi_ctx* c, float* dbuf, const float* flat, int64_t n) {
+    ARG(n == c->n_params, "flat vector length != mi_param_count");
+    std::vector<float> tmp(n);
+    for (auto& t : c->tensors) to_device_layout(t, flat + t.ref_off, tmp.data() + t.dev_off);
+    HIPC(hipMemcpyAsync(dbuf, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int download_flat(mi_ctx* c, const float* dbuf, float* flat, int64_t n) {
+    ARG(n == c->n_params, "flat vector length != mi_param_count");
+    std::vector<float> tmp(n);
+    HIPC(hipMemcpyAsync(tmp.data(), dbuf, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    for (auto& t : c->tensors) to_ref_layout(t, tmp.data() + t.dev_off, flat + t.ref_off);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ create / destroy
+template <typename T>
+static hipError_t dalloc(T** p, size_t count) {
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T) + 256);
+    if (e == hipSuccess) e = hipMemset(*p, 0, count * sizeof(T) + 256);
+    return e;
+}
+
+int mi_create(const mi_config* cfg, mi_ctx** out) {
+    ARG(cfg && out, "null cfg/out");
+    ARG(cfg->arch == MI_ARCH_IMPALA || cfg->arch == MI_ARCH_MLP, "arch");
+    ARG(cfg->n_actions >= 1 && cfg->n_actions <= 16, "n_actions must be in [1,16]");
+    ARG(cfg->n_steps >= 1 && cfg->n_envs >= 1 && cfg->max_batch >= 1, "n_steps/n_envs/max_batch");
+    if (cfg->arch == MI_ARCH_MLP) ARG(cfg->obs_dim >= 1 && cfg->mlp_depth >= 2 && cfg->mlp_width >= 1 && cfg->out_dim >= 1, "mlp dims");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "no HIP device: the MI355X library has no CPU fallback");
+    HIPC(hipSetDevice(cfg->device));
+    mi_ctx* c = new mi_ctx();
+    c->cfg = *cfg;
+    c->T = cfg->n_steps; c->E = cfg->n_envs; c->A = cfg->n_actions;
+    c->H = (cfg->arch == MI_ARCH_IMPALA) ? 256 : cfg->out_dim;
+    c->NB = cfg->max_batch < cfg->n_envs ? cfg->n_envs : cfg->max_batch;
+    if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
+    else { HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    if (cfg->arch == MI_ARCH_IMPALA) build_impala_layout(c); else build_mlp_layout(c);
+
+    const int64_t P = c->n_params, T = c->T, E = c->E, NB = c->NB;
+    HIPC(dalloc(&c->params, P)); HIPC(dalloc(&c->grads, P)); HIPC(dalloc(&c->adam_m, P)); HIPC(dalloc(&c->adam_v, P));
+    HIPC(dalloc(&c->rew, T * E)); HIPC(dalloc(&c->done, T * E)); HIPC(dalloc(&c->logp, T * E));
+    HIPC(dalloc(&c->adv, T * E)); HIPC(dalloc(&c->ret, T * E)); HIPC(dalloc(&c->value, (T + 1) * E));
+    HIPC(dalloc(&c->act, T * E)); HIPC(dalloc(&c->adv_stats, 4));
+    c->frames = nullptr; c->obsf = nullptr; c->stage_frames = nullptr; c->stage_obs = nullptr;
+    if (cfg->arch == MI_ARCH_IMPALA) {
+        c->obs_bytes_per_env = 64 * 64 * 3;
+        HIPC(dalloc(&c->frames, (size_t)(T + 1) * E * c->obs_bytes_per_env));
+        HIPC(dalloc(&c->stage_frames, (size_t)NB * c->obs_bytes_per_env));
+        const int chan[4] = {3, 16, 32, 32};
+        int hin = 64;
+        for (int b = 0; b < 3; ++b) {
+            Block& k = c->blk[b];
+            k.cin = chan[b]; k.cout = chan[b + 1]; k.hin = hin;
+            const size_t X = (size_t)NB * hin * hin * k.cout, p = X / 4;
+            HIPC(dalloc(&k.C, X)); HIPC(dalloc(&k.PI, p));
+            HIPC(dalloc(&k.P0, p)); HIPC(dalloc(&k.A1, p)); HIPC(dalloc(&k.P1, p)); HIPC(dalloc(&k.A2, p)); HIPC(dalloc(&k.P2, p));
+            hin /= 2;
+        }
+        HIPC(dalloc(&c->GC, (size_t)NB * 64 * 64 * 16));
+        for (int k = 0; k < 3; ++k) HIPC(dalloc(&c->GP[k], (size_t)NB * 32 * 32 * 16));
+        c->slab_floats = (size_t)512 * (32 * 9 * 32 + 32);
+        HIPC(dalloc(&c->slabs, c->slab_floats));
+        HIPC(dalloc(&c->fs_scratch, (size_t)64 * 2048));
+    } else {
+        c->obs_bytes_per_env = (size_t)cfg->obs_dim * sizeof(float);
+        HIPC(dalloc(&c->obsf, (size_t)(T + 1) * E * cfg->obs_dim));
+        HIPC(dalloc(&c->stage_obs, (size_t)NB * cfg->obs_dim));
+        c->mlp_act.resize(c->mlp.size() + 1);
+        HIPC(dalloc(&c->mlp_act[0], (size_t)NB * cfg->obs_dim));
+        for (size_t l = 0; l < c->mlp.size(); ++l) HIPC(dalloc(&c->mlp_act[l + 1], (size_t)NB * c->mlp[l].out));
+        c->GC = nullptr; c->slabs = nullptr; c->fs_scratch = nullptr;
+        const int wmax = cfg->mlp_width > c->H ? cfg->mlp_width : c->H;
+        for (int k = 0; k < 2; ++k) HIPC(dalloc(&c->GP[k], (size_t)NB * wmax));
+        c->GP[2] = nullptr;
+    }
+    HIPC(dalloc(&c->feat, (size_t)NB * c->H)); HIPC(dalloc(&c->dfeat, (size_t)NB * c->H));
+    HIPC(dalloc(&c->hout, (size_t)NB * (c->A + 1))); HIPC(dalloc(&c->dY, (size_t)NB * (c->A + 1)));
+    HIPC(dalloc(&c->d_lp, (size_t)NB * c->A));
+    const size_t gws = (size_t)8 << 20;
+    HIPC(dalloc(&c->gemm_ws, gws)); gemm_set_workspace(c->gemm_ws, gws);
+    HIPC(dalloc(&c->col_ws, (size_t)64 * 4096)); colsum_set_workspace(c->col_ws);
+    HIPC(dalloc(&c->fs_val, 4));
+    HIPC(dalloc(&c->lut, 256));
+    {
+        float h[256];
+        for (int k = 0; k < 256; ++k) h[k] = (float)((double)k / 255.0);   // ScaledFloatFrame: obs / 255.0 in fp64, then fp32
+        HIPC(hipMemcpy(c->lut, h, sizeof(h), hipMemcpyHostToDevice));
+    }
+    HIPC(dalloc(&c->d_idx, (size_t)NB));
+    HIPC(dalloc(&c->loss_partial, (size_t)(loss_blocks(NB) + 1) * 32));
+    HIPC(dalloc(&c->loss_stats, 64));
+    c->log_cap = 4096; c->log_count = 0;
+    HIPC(dalloc(&c->loss_log, (size_t)c->log_cap * 8));
+    HIPC(dalloc(&c->sumsq, 2)); HIPC(dalloc(&c->gnorm, 2));
+    HIPC(dalloc(&c->d_u, (size_t)E));
+    HIPC(hipHostMalloc((void**)&c->h_idx, (size_t)NB * sizeof(int32_t)));
+    c->h_f_floats = (size_t)4 * (E > 64 ? E : 64);
+    HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
+    HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
+    c->multirank = 0; c->pending_n = -1;
+    HIPC(hipDeviceSynchronize());
+    *out = c;
+    return 0;
+}
+
+int mi_destroy(mi_ctx* c) {
+    if (!c) return 0;
+    hipStreamSynchronize(c->stream);
+    float* fl[] = {c->params, c->grads, c->adam_m, c->adam_v, c->rew, c->done, c->logp, c->adv, c->ret, c->value, c->obsf,
+                   c->feat, c->dfeat, c->hout, c->dY, c->GC, c->GP[0], c->GP[1], c->GP[2], c->slabs, c->gemm_ws, c->col_ws,
+                   c->fs_scratch, c->fs_val, c->lut, c->stage_obs, c->loss_partial, c->loss_stats, c->loss_log, c->gnorm,
+                   c->d_u, c->d_lp};
+    for (float* p : fl) if (p) hipFree(p);
+    if (c->cfg.arch == MI_ARCH_IMPALA)
+        for (int b = 0; b < 3; ++b) { Block& k = c->blk[b]; hipFree(k.C); hipFree(k.PI); hipFree(k.P0); hipFree(k.A1); hipFree(k.P1); hipFree(k.A2); hipFree(k.P2); }
+    for (float* p : c->mlp_act) if (p) hipFree(p);
+    if (c->frames) hipFree(c->frames);
+    if (c->stage_frames) hipFree(c->stage_frames);
+    hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
+    hipHostFree(c->h_idx); hipHostFree(c->h_f); hipHostFree(c->h_i);
+    gemm_set_workspace(nullptr, 0);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+void* mi_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g_err = "hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+void mi_host_free(void* p) { if (p) hipHostFree(p); }
+
+int mi_sync(mi_ctx* c) { ARG(c, "ctx"); HIPC(hipStreamSynchronize(c->stream)); return 0; }
+
+int64_t mi_param_count(mi_ctx* c) { return c ? c->n_params : -1; }
+int mi_set_params(mi_ctx* c, const float* flat, int64_t n) { ARG(c && flat, "null"); return upload_flat(c, c->params, flat, n); }
+int mi_get_params(mi_ctx* c, float* flat, int64_t n) { ARG(c && flat, "null"); return download_flat(c, c->params, flat, n); }
+int mi_get_grads(mi_ctx* c, float* flat, int64_t n) { ARG(c && flat, "null"); return download_flat(c, c->grads, flat, n); }
+int mi_set_adam_state(mi_ctx* c, const float* m, const float* v, int64_t n) {
+    ARG(c && m && v, "null");
+    int r = upload_flat(c, c->adam_m, m, n);
+    return r ? r : upload_flat(c, c->adam_v, v, n);
+}
+int mi_get_adam_state(mi_ctx* c, float* m, float* v, int64_t n) {
+    ARG(c && m && v, "null");
+    int r = download_flat(c, c->adam_m, m, n);
+    return r ? r : download_flat(c, c->adam_v, v, n);
+}
+
+// ------------------------------------------------------------------------------------------ rollout storage
+int mi_put_obs(mi_ctx* c, int32_t t, const void* obs, size_t bytes) {
+    ARG(c && obs, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    const size_t want = (size_t)c->E * c->obs_bytes_per_env;
+    ARG(bytes == want, "obs byte count != E * bytes_per_env");
+    char* dst = c->frames ? (char*)c->frames : (char*)c->obsf;
+    HIPC(hipMemcpyAsync(dst + (size_t)t * want, obs, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int mi_put_step(mi_ctx* c, int32_t t, const float* rew, const float* done) {
+    ARG(c && rew && done, "null"); ARG(t >= 0 && t < c->T, "t out of range");
+    const size_t b = (size_t)c->E * sizeof(float);
+    HIPC(hipMemcpyAsync(c->rew + (size_t)t * c->E, rew, b, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemcpyAsync(c->done + (size_t)t * c->E, done, b, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int mi_put_policy_outputs(mi_ctx* c, int32_t t, const int32_t* act, const float* logp, const float* value) {
+    ARG(c, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    const size_t E = c->E;
+    if (act) { ARG(t < c->T, "act at t==T"); HIPC(hipMemcpyAsync(c->act + t * E, act, E * 4, hipMemcpyHostToDevice, c->stream)); }
+    if (logp) { ARG(t < c->T, "logp at t==T"); HIPC(hipMemcpyAsync(c->logp + t * E, logp, E * 4, hipMemcpyHostToDevice, c->stream)); }
+    if (value) HIPC(hipMemcpyAsync(c->value + t * E, value, E * 4, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));     // caller buffers may be pageable temporaries
+    return 0;
+}
+static float* field_ptr(mi_ctx* c, int f, int64_t* n) {
+    const int64_t TE = (int64_t)c->T * c->E;
+    *n = TE;
+    switch (f) {
+        case MI_F_REW: return c->rew; case MI_F_DONE: return c->done; case MI_F_LOGP: return c->logp;
+        case MI_F_ADV: return c->adv; case MI_F_RET: return c->ret;
+        case MI_F_VALUE: *n = TE + c->E; return c->value;
+        default: return nullptr;
+    }
+}
+int mi_read_field(mi_ctx* c, int32_t f, float* out, int64_t n) {
+    ARG(c && out, "null");
+    if (f == MI_F_ACT) {
+        ARG(n == (int64_t)c->T * c->E, "length");
+        std::vector<int32_t> tmp(n);
+        HIPC(hipMemcpyAsync(tmp.data(), c->act, n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        for (int64_t k = 0; k < n; ++k) out[k] = (float)tmp[k];
+        return 0;
+    }
+    int64_t want; float* p = field_ptr(c, f, &want);
+    ARG(p, "field"); ARG(n == want, "length");
+    HIPC(hipMemcpyAsync(out, p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int mi_write_field(mi_ctx* c, int32_t f, const float* in, int64_t n) {
+    ARG(c && in, "null");
+    if (f == MI_F_ACT) {
+        ARG(n == (int64_t)c->T * c->E, "length");
+        std::vector<int32_t> tmp(n);
+        for (int64_t k = 0; k < n; ++k) tmp[k] = (int32_t)in[k];
+        HIPC(hipMemcpyAsync(c->act, tmp.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    int64_t want; float* p = field_ptr(c, f, &want);
+    ARG(p, "field"); ARG(n == want, "length");
+    HIPC(hipMemcpyAsync(p, in, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ network program
+struct InputSrc { const void* base; const int32_t* idx; long long first; };   // frames or obs rows
+
+static void conv_fwd(mi_ctx* c, const ConvLayer& L, const void* in, const InputSrc* src, int relu_in, const float* res, float* out, int n) {
+    ConvArgs a{};
+    a.in = src ? src->base : in; a.idx = src ? src->idx : nullptr; a.in_base = src ? src->first : 0;
+    a.w = c->params + L.w_off; a.bias = c->params + L.b_off; a.res = res; a.mask = nullptr; a.out = out;
+    a.lut = c->lut; a.n = n; a.relu_in = relu_in;
+    launch_conv_fwd(L.shape, a, c->stream);
+}
+static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const float* mask, const float* res, float* din, int n) {
+    ConvArgs a{};
+    a.in = dout; a.w = c->params + L.w_off; a.bias = nullptr; a.res = res; a.mask = mask; a.out = din;
+    a.lut = c->lut; a.n = n; a.relu_in = 0;
+    launch_conv_dgrad(L.shape, a, c->stream);
+}
+static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const InputSrc* src, int relu_in, const float* dout, int n) {
+    WgradArgs a{};
+    a.in = src ? src->base : in; a.idx = src ? src->idx : nullptr; a.in_base = src ? src->first : 0;
+    a.dout = dout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in;
+    const int grid = wgrad_grid(L.shape, n);
+    if (grid < 1) return;
+    launch_conv_wgrad(L.shape, a, c->stream);
+    const int wlen = L.cout * 9 * L.cin;
+    launch_reduce_slabs(c->slabs, grid, wlen + L.cout, c->grads + L.w_off, wlen, c->grads + L.b_off, L.cout, c->stream);
+}
+
+static void linear_fwd(mi_ctx* c, const float* X, int relu_x, const float* W, const float* b, float* Y, int n, int in, int out, int relu_out) {
+    GemmArgs g{};
+    g.A = X; g.B = W; g.C = Y; g.M = n; g.N = out; g.K = in;
+    g.sam = in; g.sak = 1; g.sbk = 1; g.sbn = in; g.ldc = out;
+    g.bias = b; g.relu_a = relu_x; g.relu_out = relu_out;
+    launch_gemm(g, c->stream);
+}
+// dX = dY W  (* mask > 0)
+static void linear_dgrad(mi_ctx* c, const float* dY, const float* W, const float* mask, float* dX, int n, int in, int out) {
+    GemmArgs g{};
+    g.A = dY; g.B = W; g.C = dX; g.M = n; g.N = in; g.K = out;
+    g.sam = out; g.sak = 1; g.sbk = in; g.sbn = 1; g.ldc = in; g.mask = mask;
+    launch_gemm(g, c->stream);
+}
+// gW += dY^T relu?(X) ; gb += colsum(dY)
+static void linear_wgrad(mi_ctx* c, const float* dY, const float* X, int relu_x, float* gW, float* gb, int n, int in, int out) {
+    GemmArgs g{};
+    g.A = dY; g.B = X; g.C = gW; g.M = out; g.N = in; g.K = n;
+    g.sam = 1; g.sak = out; g.sbk = in; g.sbn = 1; g.ldc = in; g.relu_b = relu_x; g.accumulate = 1;
+    launch_gemm(g, c->stream);
+    launch_colsum_acc(dY, n, out, out, gb, c->stream);
+}
+
+static void net_forward(mi_ctx* c, const InputSrc& src, int n) {
+    if (c->cfg.arch == MI_ARCH_IMPALA) {
+        const float* prev = nullptr;
+        for (int b = 0; b < 3; ++b) {
+            Block& k = c->blk[b];
+            const ConvLayer* L = &c->convs[b * 5];
+            if (b == 0) conv_fwd(c, L[0], nullptr, &src, 0, nullptr, k.C, n);
+            else conv_fwd(c, L[0], prev, nullptr, 0, nullptr, k.C, n);
+            launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream);
+            conv_fwd(c, L[1], k.P0, nullptr, 1, nullptr, k.A1, n);
+            conv_fwd(c, L[2], k.A1, nullptr, 1, k.P0, k.P1, n);
+            conv_fwd(c, L[3], k.P1, nullptr, 1, nullptr, k.A2, n);
+            conv_fwd(c, L[4], k.A2, nullptr, 1, k.P1, k.P2, n);
+            prev = k.P2;
+        }
+        linear_fwd(c, c->blk[2].P2, 1, c->params + c->fc.w_off, c->params + c->fc.b_off, c->feat, n, 2048, c->H, 1);
+    } else {
+        launch_gather_rows((const float*)src.base, src.idx, src.first, c->mlp_act[0], n, c->cfg.obs_dim, c->stream);
+        const size_t L = c->mlp.size();
+        for (size_t l = 0; l < L; ++l) {
+            float* y = (l + 1 == L) ? c->feat : c->mlp_act[l + 1];
+            linear_fwd(c, c->mlp_act[l], 0, c->params + c->mlp[l].w_off, c->params + c->mlp[l].b_off, y, n, c->mlp[l].in, c->mlp[l].out, l + 1 < L);
+        }
+    }
+    linear_fwd(c, c->feat, 0, c->params + c->wh_off, c->params + c->bh_off, c->hout, n, c->H, c->A + 1, 0);
+}
+
+// backward from dY (n x (A+1)); gradients accumulate into c->grads
+static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
+    const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
+    linear_wgrad(c, c->dY, c->feat, 0, c->grads + c->wh_off, c->grads + c->bh_off, n, c->H, c->A + 1);
+    linear_dgrad(c, c->dY, c->params + c->wh_off, impala ? c->feat : nullptr, c->dfeat, n, c->H, c->A + 1);
+    if (!impala) {
+        const size_t L = c->mlp.size();
+        const float* dy = c->dfeat;
+        for (size_t l = L; l-- > 0;) {
+            linear_wgrad(c, dy, c->mlp_act[l], 0, c->grads + c->mlp[l].w_off, c->grads + c->mlp[l].b_off, n, c->mlp[l].in, c->mlp[l].out);
+            if (l == 0) break;
+            float* dx = c->GP[l & 1];
+            linear_dgrad(c, dy, c->params + c->mlp[l].w_off, c->mlp_act[l], dx, n, c->mlp[l].in, c->mlp[l].out);
+            dy = dx;
+        }
+        return;
+    }
+    linear_wgrad(c, c->dfeat, c->blk[2].P2, 1, c->grads + c->fc.w_off, c->grads + c->fc.b_off, n, 2048, c->H);
+    float* Gout = c->GP[0];
+    float* Ga = c->GP[1];
+    float* Gb = c->GP[2];
+    linear_dgrad(c, c->dfeat, c->params + c->fc.w_off, c->blk[2].P2, Gout, n, 2048, c->H);
+    for (int b = 2; b >= 0; --b) {
+        Block& k = c->blk[b];
+        const ConvLayer* L = &c->convs[b * 5];
+        // res2: P2 = conv2(relu(A2)) + P1 ; A2 = conv1(relu(P1))
+        conv_wgrad(c, L[4], k.A2, nullptr, 1, Gout, n);
+        conv_dgrad(c, L[4], Gout, k.A2, nullptr, Ga, n);
+        conv_wgrad(c, L[3], k.P1, nullptr, 1, Ga, n);
+        conv_dgrad(c, L[3], Ga, k.P1, Gout, Gb, n);
+        // res1: P1 = conv2(relu(A1)) + P0 ; A1 = conv1(relu(P0))
+        conv_wgrad(c, L[2], k.A1, nullptr, 1, Gb, n);
+        conv_dgrad(c, L[2], Gb, k.A1, nullptr, Ga, n);
+        conv_wgrad(c, L[1], k.P0, nullptr, 1, Ga, n);
+        conv_dgrad(c, L[1], Ga, k.P0, Gb, Gout, n);
+        // max pool, then the block's first conv
+        launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream);
+        if (b == 0) conv_wgrad(c, L[0], nullptr, &src, 0, c->GC, n);
+        else {
+            conv_wgrad(c, L[0], c->blk[b - 1].P2, nullptr, 0, c->GC, n);
+            conv_dgrad(c, L[0], c->GC, nullptr, nullptr, Gout, n);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ predict / forward
+int mi_policy_step(mi_ctx* c, int32_t t, uint64_t seed, const float* u, int64_t* act_out, float* logp_out, float* value_out) {
+    ARG(c, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    const int E = c->E;
+    InputSrc src{c->frames ? (const void*)c->frames : (const void*)c->obsf, nullptr, (long long)t * E};
+    const float* du = nullptr;
+    if (u) { HIPC(hipMemcpyAsync(c->d_u, u, (size_t)E * 4, hipMemcpyHostToDevice, c->stream)); du = c->d_u; }
+    net_forward(c, src, E);
+    const bool last = (t == c->T);
+    launch_sample(c->hout, E, c->A, du, seed, (unsigned long long)t * E, last ? nullptr : c->act + (size_t)t * E,
+                  last ? nullptr : c->logp + (size_t)t * E, c->value + (size_t)t * E, c->stream);
+    HIPC(hipGetLastError());
+    if (!act_out && !logp_out && !value_out) { if (u) HIPC(hipStreamSynchronize(c->stream)); return 0; }
+    if (act_out && !last) HIPC(hipMemcpyAsync(c->h_i, c->act + (size_t)t * E, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    if (logp_out && !last) HIPC(hipMemcpyAsync(c->h_f, c->logp + (size_t)t * E, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    if (value_out) HIPC(hipMemcpyAsync(c->h_f + E, c->value + (size_t)t * E, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (act_out && !last) for (int e = 0; e < E; ++e) act_out[e] = c->h_i[e];
+    if (logp_out && !last) memcpy(logp_out, c->h_f, (size_t)E * 4);
+    if (value_out) memcpy(value_out, c->h_f + E, (size_t)E * 4);
+    return 0;
+}
+
+int mi_forward(mi_ctx* c, const void* obs, int32_t n, float* logp_all, float* value, float* feat) {
+    ARG(c && obs, "null"); ARG(n >= 1 && n <= c->NB, "n must be in [1, max_batch]");
+    void* stage = c->stage_frames ? (void*)c->stage_frames : (void*)c->stage_obs;
+    HIPC(hipMemcpyAsync(stage, obs, (size_t)n * c->obs_bytes_per_env, hipMemcpyHostToDevice, c->stream));
+    InputSrc src{stage, nullptr, 0};
+    net_forward(c, src, n);
+    launch_logp_all(c->hout, n, c->A, c->d_lp, nullptr, c->stream);
+    HIPC(hipGetLastError());
+    if (logp_all) HIPC(hipMemcpyAsync(logp_all, c->d_lp, (size_t)n * c->A * 4, hipMemcpyDeviceToHost, c->stream));
+    if (feat) HIPC(hipMemcpyAsync(feat, c->feat, (size_t)n * c->H * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<float> h;
+    if (value) { h.resize((size_t)n * (c->A + 1)); HIPC(hipMemcpyAsync(h.data(), c->hout, h.size() * 4, hipMemcpyDeviceToHost, c->stream)); }
+    HIPC(hipStreamSynchronize(c->stream));
+    if (value) for (int k = 0; k < n; ++k) value[k] = h[(size_t)k * (c->A + 1) + c->A];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ estimates
+int mi_compute_estimates(mi_ctx* c, float gamma, float lmbda, int32_t use_gae, int32_t normalize_adv) {
+    ARG(c, "null");
+    launch_gae(c->rew, c->done, c->value, c->adv, c->ret, c->T, c->E, gamma, lmbda, use_gae, c->stream);
+    if (normalize_adv) {
+        launch_advnorm_stats(c->adv, c->T * c->E, c->adv_stats, c->stream);
+        launch_advnorm_apply(c->adv, c->T * c->E, c->adv_stats, c->stream);
+    }
+    HIPC(hipGetLastError());
+    return 0;
+}
+int mi_adv_stats(mi_ctx* c, double s[3]) {
+    ARG(c && s, "null");
+    launch_advnorm_stats(c->adv, c->T * c->E, c->adv_stats, c->stream);
+    HIPC(hipMemcpyAsync(s, c->adv_stats, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int mi_adv_apply(mi_ctx* c, const double s[3]) {
+    ARG(c && s, "null");
+    HIPC(hipMemcpyAsync(c->adv_stats, s, 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    launch_advnorm_apply(c->adv, c->T * c->E, c->adv_stats, c->stream);
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ minibatch / optimiser
+static InputSrc minibatch_src(mi_ctx* c) {
+    return InputSrc{c->frames ? (const void*)c->frames : (const void*)c->obsf, c->d_idx, 0};
+}
+
+int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, const mi_hparams* hp) {
+    ARG(c && hp, "null"); ARG(n >= 0 && n <= c->NB, "n_idx must be in [0, max_batch]"); ARG(n_global >= 1, "n_global");
+    ARG(n == 0 || idx, "idx");
+    ARG(c->log_count < c->log_cap, "loss log full: call mi_loss_log_read(reset=1)");
+    ARG(c->pending_n < 0, "previous multirank minibatch not finished");
+    const int64_t TE = (int64_t)c->T * c->E;
+    for (int k = 0; k < n; ++k) { ARG(idx[k] >= 0 && idx[k] < TE, "minibatch index out of range"); c->h_idx[k] = (int32_t)idx[k]; }
+    if (n) HIPC(hipMemcpyAsync(c->d_idx, c->h_idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    InputSrc src = minibatch_src(c);
+    net_forward(c, src, n);
+    const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
+    if (impala) launch_fs_metric(c->blk[2].P2, n, 2048, c->fs_scratch, c->fs_val, c->stream);
+    LossArgs a{};
+    a.hout = c->hout; a.idx = c->d_idx; a.act = c->act; a.old_logp = c->logp; a.old_value = c->value; a.ret = c->ret; a.adv = c->adv;
+    a.dY = c->dY; a.partial = c->loss_partial; a.stats = c->loss_stats; a.n = n; a.A = c->A;
+    a.inv_n_global = 1.0f / (float)n_global;
+    a.hp = LossHP{hp->eps_clip, hp->value_coef, hp->entropy_coef, hp->x_entropy_coef, hp->entropy_multiplier, hp->fs_coef};
+    launch_loss_fwd(a, c->stream);
+    float* slot = c->loss_log + (size_t)c->log_count * 8;
+    if (c->multirank) {
+        launch_loss_finalize(a, loss_blocks(n), 1, nullptr, nullptr, c->stream);
+        c->pending = a; c->pending_n = n;
+        HIPC(hipGetLastError());
+        return 0;                                   // host all-reduces loss_stats, then mi_minibatch_finish
+    }
+    launch_loss_finalize(a, loss_blocks(n), 3, impala ? c->fs_val : nullptr, slot, c->stream);
+    c->log_count++;
+    launch_loss_bwd(a, c->stream);
+    net_backward(c, src, n);
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+int mi_set_multirank(mi_ctx* c, int32_t enabled) { ARG(c, "null"); c->multirank = enabled ? 1 : 0; return 0; }
+
+int mi_minibatch_finish(mi_ctx* c) {
+    ARG(c, "null"); ARG(c->pending_n >= 0, "no pending minibatch");
+    const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
+    float* slot = c->loss_log + (size_t)c->log_count * 8;
+    launch_loss_finalize(c->pending, 0, 2, impala ? c->fs_val : nullptr, slot, c->stream);
+    c->log_count++;
+    launch_loss_bwd(c->pending, c->stream);
+    InputSrc src = minibatch_src(c);
+    net_backward(c, src, c->pending_n);
+    c->pending_n = -1;
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+int mi_optimizer_step(mi_ctx* c, float lr, float max_norm, int32_t step, float* gnorm_out) {
+    ARG(c, "null"); ARG(step >= 1, "adam_step is 1-based");
+    const double b1 = 0.9, b2 = 0.999;
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    launch_sumsq(c->grads, c->n_params, c->sumsq, c->stream);
+    launch_adam(c->params, c->grads, c->adam_m, c->adam_v, c->n_params, c->sumsq, max_norm, lr, (float)b1, (float)b2, 1e-5f,
+                step_size, bc2_sqrt, c->gnorm, c->stream);
+    HIPC(hipGetLastError());
+    if (gnorm_out) {
+        HIPC(hipMemcpyAsync(c->h_f, c->gnorm, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        *gnorm_out = c->h_f[0];
+    }
+    return 0;
+}
+
+int mi_loss_log_read(mi_ctx* c, float* out, int32_t max_records, int32_t* n_records, int32_t reset) {
+    ARG(c && n_records, "null");
+    const int n = c->log_count < max_records ? c->log_count : max_records;
+    if (out && n > 0) {
+        HIPC(hipMemcpyAsync(out, c->loss_log, (size_t)n * 8 * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    *n_records = n;
+    if (reset) c->log_count = 0;
+    return 0;
+}
+
+int mi_device_ptr(mi_ctx* c, int32_t which, void** ptr, int64_t* n) {
+    ARG(c && ptr && n, "null");
+    switch (which) {
+        case MI_PTR_GRADS: *ptr = c->grads; *n = c->n_params; return 0;
+        case MI_PTR_LOSS_STATS: *ptr = c->loss_stats; *n = 32; return 0;
+        case MI_PTR_PARAMS: *ptr = c->params; *n = c->n_params; return 0;
+        default: return fail(-1, "unknown pointer id");
+    }
+}
+
+// ------------------------------------------------------------------------------------------ op-level test entry points
+static int shape_of(int cin, int cout, int hw, ConvShape* s) {
+    for (int k = 0; k < CS_COUNT; ++k) {
+        int a, b, h; conv_shape_dims((ConvShape)k, &a, &b, &h);
+        if (a == cin && b == cout && h == hw) { *s = (ConvShape)k; return 0; }
+    }
+    return fail(-1, "unsupported conv shape");
+}
+
+int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw, int32_t n, const void* in, int32_t in_is_u8,
+                  int32_t relu_in, const float* w_ref, const float* bias, const float* res, const float* mask, const float* dout,
+                  float* out, float* dbias_out) {
+    ARG(c && w_ref && out && n >= 1, "null");
+    ConvShape s;
+    if (shape_of(cin, cout, hw, &s)) return -1;
+    ARG((s == CS_3_16_64) == (in_is_u8 != 0) || mode == 1, "block1.conv takes uint8 frames");
+    const size_t px = (size_t)n * hw * hw;
+    TensorDesc td{"w", 0, 0, (int64_t)cout * cin * 9, K_CONVW, cout, cin};
+    std::vector<float> wdev(td.n);
+    to_device_layout(td, w_ref, wdev.data());
+    float *dw = nullptr, *db = nullptr, *din = nullptr, *dres = nullptr, *dmask = nullptr, *ddout = nullptr, *dout_buf = nullptr;
+    HIPC(dalloc(&dw, td.n)); HIPC(hipMemcpy(dw, wdev.data(), td.n * 4, hipMemcpyHostToDevice));
+    if (bias) { HIPC(dalloc(&db, cout)); HIPC(hipMemcpy(db, bias, cout * 4, hipMemcpyHostToDevice)); }
+    const int in_ch = (mode == 1) ? cout : cin, out_ch = (mode == 1) ? cin : cout;
+    if (mode != 1) {
+        const size_t ib = in_is_u8 ? px * 3 : px * cin * 4;
+        HIPC(hipMalloc((void**)&din, ib + 256)); HIPC(hipMemcpy(din, in, ib, hipMemcpyHostToDevice));
+    }
+    if (mode >= 1) { ARG(dout, "dout"); HIPC(dalloc(&ddout, px * cout)); HIPC(hipMemcpy(ddout, dout, px * cout * 4, hipMemcpyHostToDevice)); }
+    if (res) { HIPC(dalloc(&dres, px * out_ch)); HIPC(hipMemcpy(dres, res, px * out_ch * 4, hipMemcpyHostToDevice)); }
+    if (mask) { HIPC(dalloc(&dmask, px * out_ch)); HIPC(hipMemcpy(dmask, mask, px * out_ch * 4, hipMemcpyHostToDevice)); }
+    (void)in_ch;
+    if (mode <= 1) {
+        HIPC(dalloc(&dout_buf, px * out_ch));
+        ConvArgs a{};
+        a.in = (mode == 0) ? (const void*)din : (const void*)ddout; a.idx = nullptr; a.in_base = 0; a.w = dw; a.bias = (mode == 0) ? db : nullptr;
+        a.res = dres; a.mask = dmask; a.out = dout_buf; a.lut = c->lut; a.n = n; a.relu_in = (mode == 0) ? relu_in : 0;
+        if (mode == 0) launch_conv_fwd(s, a, c->stream); else launch_conv_dgrad(s, a, c->stream);
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(c->stream));
+        HIPC(hipMemcpy(out, dout_buf, px * out_ch * 4, hipMemcpyDeviceToHost));
+    } else {
+        ARG(c->slabs, "wgrad needs an IMPALA context");
+        float* g = nullptr;
+        HIPC(dalloc(&g, td.n + cout));
+        WgradArgs a{};
+        a.in = din; a.idx = nullptr; a.in_base = 0; a.dout = ddout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in;
+        const int grid = wgrad_grid(s, n);
+        launch_conv_wgrad(s, a, c->stream);
+        launch_reduce_slabs(c->slabs, grid, (int)td.n + cout, g, (int)td.n, g + td.n, cout, c->stream);
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(c->stream));
+        std::vector<float> hg(td.n + cout);
+        HIPC(hipMemcpy(hg.data(), g, hg.size() * 4, hipMemcpyDeviceToHost));
+        to_ref_layout(td, hg.data(), out);
+        if (dbias_out) memcpy(dbias_out, hg.data() + td.n, cout * 4);
+        hipFree(g);
+    }
+    float* fr[] = {dw, db, din, dres, dmask, ddout, dout_buf};
+    for (float* p : fr) if (p) hipFree(p);
+    return 0;
+}
+
+int mi_op_maxpool(mi_ctx* c, int32_t mode, int32_t n, int32_t hw, int32_t ch, const float* in, const float* dout, float* out) {
+    ARG(c && in && out, "null");
+    const size_t X = (size_t)n * hw * hw * ch, p = X / 4;
+    float *din = nullptr, *dp = nullptr, *dd = nullptr, *dg = nullptr; uint8_t* di = nullptr;
+    HIPC(dalloc(&din, X)); HIPC(dalloc(&dp, p)); HIPC(dalloc(&di, p));
+    HIPC(hipMemcpy(din, in, X * 4, hipMemcpyHostToDevice));
+    launch_maxpool_fwd(din, dp, di, n, hw, ch, c->stream);
+    if (mode == 0) { HIPC(hipStreamSynchronize(c->stream)); HIPC(hipMemcpy(out, dp, p * 4, hipMemcpyDeviceToHost)); }
+    else {
+        ARG(dout, "dout");
+        HIPC(dalloc(&dd, p)); HIPC(dalloc(&dg, X));
+        HIPC(hipMemcpy(dd, dout, p * 4, hipMemcpyHostToDevice));
+        launch_maxpool_bwd(dd, di, dg, n, hw, ch, c->stream);
+        HIPC(hipStreamSynchronize(c->stream));
+        HIPC(hipMemcpy(out, dg, X * 4, hipMemcpyDeviceToHost));
+    }
+    HIPC(hipGetLastError());
+    hipFree(din); hipFree(dp); hipFree(di); if (dd) hipFree(dd); if (dg) hipFree(dg);
+    return 0;
+}
+
+int mi_op_gemm(mi_ctx* c, int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
+               int64_t sbn, float* C) {
+    ARG(c && A && B && C, "null");
+    const size_t na = (size_t)((M - 1) * sam + (K - 1) * sak + 1), nb = (size_t)((K - 1) * sbk + (N - 1) * sbn + 1);
+    float *da = nullptr, *db = nullptr, *dc = nullptr;
+    HIPC(dalloc(&da, na)); HIPC(dalloc(&db, nb)); HIPC(dalloc(&dc, (size_t)M * N));
+    HIPC(hipMemcpy(da, A, na * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(db, B, nb * 4, hipMemcpyHostToDevice));
+    GemmArgs g{};
+    g.A = da; g.B = db; g.C = dc; g.M = M; g.N = N; g.K = K; g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = N;
+    launch_gemm(g, c->stream);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpy(C, dc, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dc);
+    return 0;
+}
+
+// D = A(16x4) * B(4x16) with asymmetric integer data through the operand maps the kernels assume:
+// A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D[row = (lane>>4)*4 + r][col = lane&15]
+__global__ void mfma_selftest_kernel(float* d) {
+    const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+    const float a = (float)(i * 7 + q * 3 + 1), b = (float)(q * 5 - i * 2 + 11);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) d[(q * 4 + r) * 16 + i] = acc[r];
+}
+int mi_selftest_mfma(mi_ctx* c, float* max_err) {
+    ARG(c && max_err, "null");
+    float* d = nullptr;
+    HIPC(dalloc(&d, 256));
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, c->stream, d);
+    HIPC(hipStreamSynchronize(c->stream));
+    float h[256];
+    HIPC(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    hipFree(d);
+    float worst = 0.f;
+    for (int m = 0; m < 16; ++m)
+        for (int n = 0; n < 16; ++n) {
+            float ref = 0.f;
+            for (int k = 0; k < 4; ++k) ref += (float)(m * 7 + k * 3 + 1) * (float)(k * 5 - n * 2 + 11);
+            worst = fmaxf(worst, fabsf(ref - h[m * 16 + n]));
+        }
+    *max_err = worst;
+    return 0;
+}

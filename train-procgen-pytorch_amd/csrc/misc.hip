@@ -1,0 +1,569 @@
+// HBM-bound scan / elementwise / reduction kernels of the PPO path and the generic MFMA GEMM used
+// by the linear layers.  gfx950 only (64-lane waves).  Every reduction has a fixed summation
+// order: results are bitwise reproducible run to run (no float atomics anywhere).
+#include "common.h"
+#include <math.h>
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+// sum over a 256-thread block, result valid in thread 0; sbuf >= 4 entries
+template <typename T>
+__device__ __forceinline__ T block_sum256(T v, T* sbuf) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sbuf[w] = v;
+    __syncthreads();
+    return sbuf[0] + sbuf[1] + sbuf[2] + sbuf[3];
+}
+
+// ------------------------------------------------------------------------------------------ GEMM
+// 64x64 output tile per workgroup, K tile 16, four waves as 2x2 of 32x32; K permuted so that lane
+// quarter q owns k = 4q..4q+3 of the K tile (one ds_read_b128 per operand per 4 MFMAs).
+// Used for: embedder.fc, the policy/value heads and the MLP embedder (forward, dgrad, wgrad) --
+// nn.Linear in common/model.py:176,199 / :966-971 and common/policy.py:39-40,75,80.
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int k_chunk, float* ws) {
+    __shared__ __attribute__((aligned(16))) float As[64 * 20];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * 20];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * k_chunk, kend = min(g.K, kbeg + k_chunk);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool a_kc = (g.sak == 1), b_kc = (g.sbk == 1);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int l = tid + e * 256;
+            int m, k;
+            if (a_kc) { m = l >> 4; k = l & 15; } else { m = l & 63; k = l >> 6; }
+            float v = 0.f;
+            if (m0 + m < g.M && k0 + k < kend) { v = g.A[(long long)(m0 + m) * g.sam + (long long)(k0 + k) * g.sak]; if (g.relu_a) v = fmaxf(v, 0.f); }
+            As[m * 20 + k] = v;
+            int n;
+            if (b_kc) { n = l >> 4; k = l & 15; } else { n = l & 63; k = l >> 6; }
+            v = 0.f;
+            if (n0 + n < g.N && k0 + k < kend) { v = g.B[(long long)(k0 + k) * g.sbk + (long long)(n0 + n) * g.sbn]; if (g.relu_b) v = fmaxf(v, 0.f); }
+            Bs[n * 20 + k] = v;
+        }
+        __syncthreads();
+        f32x4 av[2], bv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) av[a] = *(const f32x4*)(As + (wm * 32 + a * 16 + i) * 20 + q * 4);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bv[b] = *(const f32x4*)(Bs + (wn * 32 + b * 16 + i) * 20 + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(av[a][e], bv[b][e], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + a * 16 + q * 4 + r, n = n0 + wn * 32 + b * 16 + i;
+                if (m < g.M && n < g.N) {
+                    float v = acc[a][b][r];
+                    if (ws) { ws[((long long)blockIdx.z * g.M + m) * g.N + n] = v; continue; }
+                    const long long o = (long long)m * g.ldc + n;
+                    if (g.bias) v += g.bias[n];
+                    if (g.relu_out) v = fmaxf(v, 0.f);
+                    if (g.mask) v = g.mask[o] > 0.f ? v : 0.f;
+                    if (g.accumulate) v += g.C[o];
+                    g.C[o] = v;
+                }
+            }
+}
+
+__global__ void gemm_splitk_reduce(const float* ws, int split, int M, int N, float* C, long long ldc, int accumulate) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < split; ++z) s += ws[(long long)z * M * N + e];
+    const long long o = (e / N) * ldc + (e % N);
+    C[o] = accumulate ? C[o] + s : s;
+}
+
+static float* g_gemm_ws = nullptr;
+static size_t g_gemm_ws_floats = 0;
+void gemm_set_workspace(float* ws, size_t floats) { g_gemm_ws = ws; g_gemm_ws_floats = floats; }
+
+void launch_gemm(const GemmArgs& g, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return;
+    const int tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
+    int split = 1;
+    // weight-gradient shapes: few output tiles, long K (= batch).  Split K over workgroups and add
+    // the slabs in a fixed order (only plain accumulate epilogues use this path).
+    if (!g.bias && !g.mask && !g.relu_out && g.K >= 1024 && tm * tn < 256 && g_gemm_ws) {
+        split = 512 / (tm * tn);
+        if (split > g.K / 256) split = g.K / 256;
+        if (split < 1) split = 1;
+        while (split > 1 && (size_t)split * g.M * g.N > g_gemm_ws_floats) --split;
+    }
+    int k_chunk = ((g.K + split - 1) / split + 15) / 16 * 16;
+    if (split == 1) {
+        hipLaunchKernelGGL(gemm_kernel, dim3(tn, tm, 1), dim3(256), 0, st, g, k_chunk, (float*)nullptr);
+    } else {
+        split = (g.K + k_chunk - 1) / k_chunk;
+        hipLaunchKernelGGL(gemm_kernel, dim3(tn, tm, split), dim3(256), 0, st, g, k_chunk, g_gemm_ws);
+        const long long tot = (long long)g.M * g.N;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
+                           (const float*)g_gemm_ws, split, g.M, g.N, g.C, g.ldc, g.accumulate);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ max pool 3/2/1
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (common/model.py:158), NHWC.  The winner is the
+// FIRST maximum in (ky,kx) scan order (strict >), which is where torch's CPU kernel routes the
+// gradient; its window-relative position is kept as one byte per output for the backward pass.
+__global__ void maxpool_fwd_kernel(const float* in, float* out, uint8_t* arg, int n, int hw, int c) {
+    const int ho = hw / 2;
+    const long long tot = (long long)n * ho * ho * c;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= tot) return;
+    const int ch = e % c;
+    long long r = e / c;
+    const int ox = r % ho; r /= ho;
+    const int oy = r % ho; const long long img = r / ho;
+    float best = -INFINITY;
+    int bi = 0;
+    bool first = true;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int y = 2 * oy - 1 + ky, x = 2 * ox - 1 + kx;
+            if (y < 0 || y >= hw || x < 0 || x >= hw) continue;
+            const float v = in[((img * hw + y) * hw + x) * c + ch];
+            if (first || v > best || v != v) { best = v; bi = ky * 3 + kx; first = false; }
+        }
+    out[e] = best;
+    arg[e] = (uint8_t)bi;
+}
+
+__global__ void maxpool_bwd_kernel(const float* dout, const uint8_t* arg, float* din, int n, int hw, int c) {
+    const int ho = hw / 2;
+    const long long tot = (long long)n * hw * hw * c;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= tot) return;
+    const int ch = e % c;
+    long long r = e / c;
+    const int x = r % hw; r /= hw;
+    const int y = r % hw; const long long img = r / hw;
+    float s = 0.f;
+    // windows oy with 2*oy-1 <= y <= 2*oy+1
+    for (int oy = y / 2; oy <= (y + 1) / 2; ++oy) {
+        if (oy >= ho) continue;
+        for (int ox = x / 2; ox <= (x + 1) / 2; ++ox) {
+            if (ox >= ho) continue;
+            const long long o = ((img * ho + oy) * ho + ox) * c + ch;
+            const int pos = (y - (2 * oy - 1)) * 3 + (x - (2 * ox - 1));
+            if (arg[o] == pos) s += dout[o];
+        }
+    }
+    din[e] = s;
+}
+
+void launch_maxpool_fwd(const float* in, float* out, uint8_t* arg, int n, int hw, int c, hipStream_t st) {
+    const long long tot = (long long)n * (hw / 2) * (hw / 2) * c;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, in, out, arg, n, hw, c);
+}
+void launch_maxpool_bwd(const float* dout, const uint8_t* arg, float* din, int n, int hw, int c, hipStream_t st) {
+    const long long tot = (long long)n * hw * hw * c;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dout, arg, din, n, hw, c);
+}
+
+// ------------------------------------------------------------------------------------------ slab / column reductions
+__global__ void reduce_slabs_kernel(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= slab_len) return;
+    float s = 0.f;
+    for (int b = 0; b < nslab; ++b) s += partial[(long long)b * slab_len + e];
+    if (e < n_w) dst_w[e] += s;
+    else if (e - n_w < n_b) dst_b[e - n_w] += s;
+}
+void launch_reduce_slabs(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b, hipStream_t st) {
+    if (nslab <= 0) return;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((slab_len + 255) / 256), dim3(256), 0, st, partial, nslab, slab_len, dst_w, n_w, dst_b, n_b);
+}
+
+// db[n] += sum_m dY[m][n]   (bias gradients of the linear layers); 64 row groups x fixed order
+__global__ void colsum_partial_kernel(const float* dY, int M, int N, int ld, float* part) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), rg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int groups = gridDim.y * 4;
+    float s = 0.f;
+    if (n < N) for (int m = rg; m < M; m += groups) s += dY[(long long)m * ld + n];
+    if (n < N) part[(long long)rg * N + n] = s;
+}
+static float* g_col_ws = nullptr;
+void colsum_set_workspace(float* ws) { g_col_ws = ws; }
+void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, hipStream_t st) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, 16), dim3(256), 0, st, dY, M, N, ld, g_col_ws);
+    launch_reduce_slabs(g_col_ws, 64, N, db, N, nullptr, 0, st);
+}
+
+__global__ void gather_rows_kernel(const float* src, const int32_t* idx, long long base, float* dst, int n, int d) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)n * d) return;
+    const int s = e / d, c = e % d;
+    const long long row = idx ? (long long)idx[s] : base + s;
+    dst[e] = src[row * d + c];
+}
+void launch_gather_rows(const float* src, const int32_t* idx, long long base, float* dst, int n, int d, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(((long long)n * d + 255) / 256)), dim3(256), 0, st, src, idx, base, dst, n, d);
+}
+
+__global__ void fill_kernel(float* p, long long n, float v) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) p[e] = v;
+}
+void launch_fill(float* p, long long n, float v, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+}
+
+// ------------------------------------------------------------------------------------------ PPO loss
+// agents/ppo.py:131-169 + cross_batch_entropy (common/misc_util.py:42-51), forward statistics and
+// the analytic gradient wrt (logits, value).  One thread per sample; A <= 16.
+#define MAXA 16
+struct SampleTerms {
+    float lp[MAXA], p[MAXA];
+    float H, ratio, adv, surr1, surr2, v, oldv, ret, vclip, vs1, vs2;
+    int act;
+};
+__device__ __forceinline__ void log_softmax_twice(const float* z, int A, float* lp, float* p) {
+    float mx = z[0];
+    for (int a = 1; a < A; ++a) mx = fmaxf(mx, z[a]);
+    float s = 0.f;
+    for (int a = 0; a < A; ++a) s += expf(z[a] - mx);
+    const float lse = mx + logf(s);
+    float s2 = 0.f;
+    for (int a = 0; a < A; ++a) { lp[a] = z[a] - lse; s2 += expf(lp[a]); }
+    const float lse2 = logf(s2);                 // Categorical(logits=log_probs) normalises again (policy.py:86-87)
+    float s3 = 0.f;
+    for (int a = 0; a < A; ++a) { lp[a] -= lse2; p[a] = expf(lp[a]); s3 += p[a]; }
+    for (int a = 0; a < A; ++a) p[a] /= s3;       // Categorical.probs = softmax(logits)
+}
+__device__ __forceinline__ void sample_terms(const LossArgs& a, int s, SampleTerms& t) {
+    const float* h = a.hout + (long long)s * (a.A + 1);
+    float z[MAXA];
+    for (int k = 0; k < a.A; ++k) z[k] = h[k];
+    log_softmax_twice(z, a.A, t.lp, t.p);
+    const int gi = a.idx[s];
+    t.act = a.act[gi];
+    t.adv = a.adv[gi]; t.ret = a.ret[gi]; t.oldv = a.old_value[gi];
+    t.v = h[a.A];
+    float H = 0.f;
+    for (int k = 0; k < a.A; ++k) H -= t.p[k] * t.lp[k];
+    t.H = H;
+    t.ratio = expf(t.lp[t.act] - a.old_logp[gi]);
+    t.surr1 = t.ratio * t.adv;
+    t.surr2 = fminf(fmaxf(t.ratio, 1.f - a.hp.eps_clip), 1.f + a.hp.eps_clip) * t.adv;
+    t.vclip = t.oldv + fminf(fmaxf(t.v - t.oldv, -a.hp.eps_clip), a.hp.eps_clip);
+    t.vs1 = (t.v - t.ret) * (t.v - t.ret);
+    t.vs2 = (t.vclip - t.ret) * (t.vclip - t.ret);
+}
+
+int loss_blocks(int n) { return (n + 255) / 256; }
+
+__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a) {
+    __shared__ float sb[4];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    SampleTerms t;
+    float pi = 0.f, vm = 0.f, H = 0.f;
+    float pa[MAXA];
+    for (int k = 0; k < MAXA; ++k) pa[k] = 0.f;
+    if (s < a.n) {
+        sample_terms(a, s, t);
+        pi = fminf(t.surr1, t.surr2);
+        vm = fmaxf(t.vs1, t.vs2);
+        H = t.H;
+        for (int k = 0; k < a.A; ++k) pa[k] = t.p[k];
+    }
+    float* out = a.partial + (long long)blockIdx.x * (8 + a.A);
+    float r = block_sum256(pi, sb); if (threadIdx.x == 0) out[0] = r;
+    r = block_sum256(vm, sb);       if (threadIdx.x == 0) out[1] = r;
+    r = block_sum256(H, sb);        if (threadIdx.x == 0) out[2] = r;
+    for (int k = 0; k < a.A; ++k) { r = block_sum256(pa[k], sb); if (threadIdx.x == 0) out[8 + k] = r; }
+}
+void launch_loss_fwd(const LossArgs& a, hipStream_t st) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(loss_blocks(a.n)), dim3(256), 0, st, a);
+}
+
+// phase 1: block partials -> this rank's contribution to the GLOBAL-minibatch means (x inv_n_global)
+// phase 2: (after the optional cross-rank sum of stats[0..2], stats[8..8+A)) derived terms + log record
+__global__ void loss_finalize_kernel(LossArgs a, int nblk, int phase, const float* fs_ptr, float* log_slot) {
+    const int k = threadIdx.x;
+    if (phase & 1) {
+        if (k < 3 || (k >= 8 && k < 8 + a.A)) {
+            float s = 0.f;
+            for (int b = 0; b < nblk; ++b) s += a.partial[(long long)b * (8 + a.A) + k];
+            s *= a.inv_n_global;
+            if (k == 0) s = -s;            // pi_loss = -mean(min(surr1,surr2))
+            if (k == 1) s = 0.5f * s;      // value_loss = 0.5*mean(max(..))
+            a.stats[k] = s;
+        }
+        __syncthreads();
+    }
+    if ((phase & 2) && k == 0) {
+        float marg = 0.f;
+        for (int j = 0; j < a.A; ++j) { const float qj = a.stats[8 + j]; marg -= qj * logf(qj); }
+        const float ent = a.stats[2], xent = marg - ent;
+        const float fs = fs_ptr ? fs_ptr[0] : 0.f;
+        const float total = a.stats[0] + a.hp.value_coef * a.stats[1] - a.hp.entropy_coef * ent * a.hp.entropy_mult
+                            - a.hp.x_entropy_coef * xent + a.hp.fs_coef * fs;
+        a.stats[3] = xent; a.stats[4] = total; a.stats[5] = fs; a.stats[6] = marg;
+        if (log_slot) {
+            log_slot[0] = a.stats[0]; log_slot[1] = a.stats[1]; log_slot[2] = ent; log_slot[3] = xent;
+            log_slot[4] = total; log_slot[5] = fs; log_slot[6] = marg; log_slot[7] = 0.f;
+        }
+    }
+}
+void launch_loss_finalize(const LossArgs& a, int nblk, int phase, const float* fs_ptr, float* log_slot, hipStream_t st) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a, nblk, phase, fs_ptr, log_slot);
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n) return;
+    SampleTerms t;
+    sample_terms(a, s, t);
+    const float ib = a.inv_n_global;
+    // d pi_loss / d logp_act  (torch.min routes to surr1 on <=; a tie is the unclipped regime where both
+    // branches carry adv/2 each; clamp passes gradient inside [1-eps, 1+eps])
+    const float g_lp = -ib * ((t.surr1 <= t.surr2) ? t.adv : 0.f) * t.ratio;
+    const float cH = (-a.hp.entropy_coef * a.hp.entropy_mult + a.hp.x_entropy_coef) * ib;
+    float plq = 0.f;
+    float lq[MAXA];
+    const bool xe = a.hp.x_entropy_coef != 0.f;
+    if (xe) for (int k = 0; k < a.A; ++k) { lq[k] = logf(a.stats[8 + k]); plq += t.p[k] * lq[k]; }
+    float* d = a.dY + (long long)s * (a.A + 1);
+    for (int k = 0; k < a.A; ++k) {
+        float gk = g_lp * ((k == t.act ? 1.f : 0.f) - t.p[k]);
+        gk += cH * (-t.p[k] * (t.lp[k] + t.H));
+        if (xe) gk += a.hp.x_entropy_coef * ib * t.p[k] * (lq[k] - plq);
+        d[k] = gk;
+    }
+    const float dvl = t.v - t.oldv;
+    const float inr = (dvl >= -a.hp.eps_clip && dvl <= a.hp.eps_clip) ? 1.f : 0.f;
+    float gv;
+    if (t.vs1 > t.vs2) gv = 2.f * (t.v - t.ret);
+    else if (t.vs2 > t.vs1) gv = 2.f * (t.vclip - t.ret) * inr;
+    else gv = (t.v - t.ret) + (t.vclip - t.ret) * inr;
+    d[a.A] = a.hp.value_coef * 0.5f * ib * gv;
+}
+void launch_loss_bwd(const LossArgs& a, hipStream_t st) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(loss_blocks(a.n)), dim3(256), 0, st, a);
+}
+
+// feature-sparsity metric (common/model.py:207): mean_j max_b tanh(|100*relu(h_bj)|)
+// = mean_j tanh(100 * max_b relu(h_bj)) (tanh monotone).  flat_pre is block3's output BEFORE the ReLU.
+__global__ void colmax_partial_kernel(const float* x, int n, int d, float* part) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), rg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int groups = gridDim.y * 4;
+    float m = 0.f;
+    if (j < d) { for (int b = rg; b < n; b += groups) m = fmaxf(m, x[(long long)b * d + j]); part[(long long)rg * d + j] = m; }
+}
+__global__ __launch_bounds__(256) void fs_finalize_kernel(const float* part, int groups, int d, float* fs_out) {
+    __shared__ double sb[4];
+    double s = 0.0;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        float m = 0.f;
+        for (int g = 0; g < groups; ++g) m = fmaxf(m, part[(long long)g * d + j]);
+        s += (double)tanhf(fabsf(m * 100.f));
+    }
+    const double tot = block_sum256(s, sb);
+    if (threadIdx.x == 0) fs_out[0] = (float)(tot / d);
+}
+void launch_fs_metric(const float* flat_pre, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(colmax_partial_kernel, dim3((d + 63) / 64, 16), dim3(256), 0, st, flat_pre, n, d, colmax_scratch);
+    hipLaunchKernelGGL(fs_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)colmax_scratch, 64, d, fs_out);
+}
+
+// ------------------------------------------------------------------------------------------ GAE scan
+// Storage.compute_estimates (common/storage.py:56-77).  One thread per env (coalesced over E),
+// serial over T; fp contraction off so every operation rounds exactly like the reference's
+// separate fp32 tensor ops (bit-exact advantages/returns).
+__global__ void gae_kernel(const float* rew, const float* done, const float* value, float* adv, float* ret, int T, int E,
+                           float gamma, float gl, int use_gae) {
+#pragma clang fp contract(off)
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float A = 0.f;
+    for (int i = T - 1; i >= 0; --i) {
+        const long long o = (long long)i * E + e;
+        float a_i = 0.f;
+        if (use_gae) {
+            const float nd = 1.f - done[o];
+            const float delta = (rew[o] + (gamma * value[o + E]) * nd) - value[o];
+            A = ((gl * A) * nd) + delta;
+            a_i = A;
+        }
+        adv[o] = a_i;
+        ret[o] = a_i + value[o];           // use_gae=False: return = adv(=0) + V (the reference's overwrite, storage.py:77)
+    }
+}
+void launch_gae(const float* rew, const float* done, const float* value, float* adv, float* ret, int T, int E,
+                float gamma, float lmbda, int use_gae, hipStream_t st) {
+    const float gl = (float)((double)gamma * (double)lmbda);
+    hipLaunchKernelGGL(gae_kernel, dim3((E + 63) / 64), dim3(64), 0, st, rew, done, value, adv, ret, T, E, gamma, gl, use_gae);
+}
+
+// advantage normalisation (common/storage.py:78-79): (A - mean) / (std_unbiased + 1e-8).
+// stats3 = {count, mean, M2} in fp64 so that ranks can merge them (Chan) before apply.
+__global__ __launch_bounds__(1024) void advnorm_stats_kernel(const float* adv, int n, double* stats3) {
+    __shared__ double sb[16];
+    __shared__ double s_mean;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double s = 0.0;
+    for (int k = tid; k < n; k += 1024) s += (double)adv[k];
+    s = wave_sum(s);
+    if (lane == 0) sb[w] = s;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int k = 0; k < 16; ++k) t += sb[k]; s_mean = n > 0 ? t / n : 0.0; }
+    __syncthreads();
+    const double mean = s_mean;
+    double m2 = 0.0;
+    for (int k = tid; k < n; k += 1024) { const double d = (double)adv[k] - mean; m2 += d * d; }
+    m2 = wave_sum(m2);
+    __syncthreads();
+    if (lane == 0) sb[w] = m2;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int k = 0; k < 16; ++k) t += sb[k]; stats3[0] = (double)n; stats3[1] = mean; stats3[2] = t; }
+}
+__global__ void advnorm_apply_kernel(float* adv, int n, const double* stats3) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float mean = (float)stats3[1];
+    const float sd = (float)sqrt(stats3[2] / (stats3[0] - 1.0));
+    adv[k] = (adv[k] - mean) / (sd + 1e-8f);
+}
+void launch_advnorm_stats(const float* adv, int n, double* stats3, hipStream_t st) {
+    hipLaunchKernelGGL(advnorm_stats_kernel, dim3(1), dim3(1024), 0, st, adv, n, stats3);
+}
+void launch_advnorm_apply(float* adv, int n, const double* stats3, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(advnorm_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, st, adv, n, stats3);
+}
+
+// ------------------------------------------------------------------------------------------ rollout head: sample
+// agents/ppo.py:77-79: dist.sample(), dist.log_prob(act).  Inverse-CDF over the A probabilities with a
+// uniform from a caller-supplied array (tests) or Philox4x32-10 keyed by (seed, counter + env).
+__device__ __forceinline__ void philox_round(uint32_t* c, uint32_t* k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);     // [0,1), 24 bits
+}
+__global__ void sample_kernel(const float* hout, int n, int A, const float* u, unsigned long long seed,
+                              unsigned long long ctr, int32_t* act, float* logp, float* value) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* h = hout + (long long)e * (A + 1);
+    float z[MAXA], lp[MAXA], p[MAXA];
+    for (int k = 0; k < A; ++k) z[k] = h[k];
+    log_softmax_twice(z, A, lp, p);
+    const float uu = u ? u[e] : philox_uniform(seed, ctr + e);
+    float cdf = 0.f;
+    int a_sel = 0;
+    for (int k = 0; k < A; ++k) { cdf += expf(lp[k]); if (cdf <= uu) a_sel = k + 1; }
+    if (a_sel > A - 1) a_sel = A - 1;
+    if (act) act[e] = a_sel;
+    if (logp) logp[e] = lp[a_sel];
+    if (value) value[e] = h[A];
+}
+__global__ void logp_all_kernel(const float* hout, int n, int A, float* lp_out, float* value_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* h = hout + (long long)e * (A + 1);
+    float z[MAXA], lp[MAXA], p[MAXA];
+    for (int k = 0; k < A; ++k) z[k] = h[k];
+    log_softmax_twice(z, A, lp, p);
+    if (lp_out) for (int k = 0; k < A; ++k) lp_out[(long long)e * A + k] = lp[k];
+    if (value_out) value_out[e] = h[A];
+}
+void launch_logp_all(const float* hout, int n, int A, float* lp_out, float* value_out, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(logp_all_kernel, dim3((n + 63) / 64), dim3(64), 0, st, hout, n, A, lp_out, value_out);
+}
+void launch_sample(const float* hout, int n, int A, const float* u, unsigned long long seed, unsigned long long ctr,
+                   int32_t* act, float* logp, float* value, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(sample_kernel, dim3((n + 63) / 64), dim3(64), 0, st, hout, n, A, u, seed, ctr, act, logp, value);
+}
+
+// ------------------------------------------------------------------------------------------ clip + Adam
+// torch.nn.utils.clip_grad_norm_(params, c) + optim.Adam(eps=1e-5).step() + zero_grad() (agents/ppo.py:174-176)
+// over the flat parameter / gradient / moment buffers.
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* g, long long n, double* out) {
+    __shared__ double sb[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double s = 0.0;
+    for (long long k = tid; k < n; k += 1024) { const double x = (double)g[k]; s += x * x; }
+    s = wave_sum(s);
+    if (lane == 0) sb[w] = s;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int k = 0; k < 16; ++k) t += sb[k]; out[0] = t; }
+}
+void launch_sumsq(const float* g, long long n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, st, g, n, out);
+}
+__global__ void adam_kernel(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr_unused,
+                            float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float* gnorm_out) {
+#pragma clang fp contract(off)
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float norm = (float)sqrt(sumsq[0]);
+    float coef = max_norm / (norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    if (k == 0 && gnorm_out) gnorm_out[0] = norm;
+    if (k >= n) return;
+    const float gk = g[k] * coef;
+    float mk = m[k], vk = v[k];
+    mk = mk + (gk - mk) * (1.f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+    vk = vk * beta2 + ((1.f - beta2) * gk) * gk;         // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
+    const float denom = sqrtf(vk) / bc2_sqrt + eps;
+    p[k] = p[k] + (-step_size) * (mk / denom);           // param.addcdiv_(exp_avg, denom, value=-step_size)
+    m[k] = mk; v[k] = vk;
+    g[k] = 0.f;                                          // optimizer.zero_grad()
+}
+void launch_adam(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr,
+                 float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float* gnorm_out, hipStream_t st) {
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, sumsq, max_norm, lr,
+                       beta1, beta2, eps, step_size, bc2_sqrt, gnorm_out);
+}

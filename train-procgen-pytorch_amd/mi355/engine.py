@@ -1,0 +1,284 @@
+"""Thin ctypes layer over the C ABI in include/mi355ppo.h.
+
+There is deliberately NO fallback: if libmi355ppo.so is missing or no MI355X is visible, creating an
+Engine raises.  (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ARCH_IMPALA, ARCH_MLP = 0, 1
+F_REW, F_DONE, F_VALUE, F_LOGP, F_ADV, F_RET, F_ACT = range(7)
+PTR_GRADS, PTR_LOSS_STATS, PTR_PARAMS = 0, 1, 2
+LOSS_FIELDS = ("pi_loss", "value_loss", "entropy", "x_ent", "total", "fs", "marg", "_pad")
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("arch", C.c_int32), ("n_steps", C.c_int32), ("n_envs", C.c_int32), ("n_actions", C.c_int32),
+                ("obs_dim", C.c_int32), ("mlp_depth", C.c_int32), ("mlp_width", C.c_int32), ("out_dim", C.c_int32),
+                ("max_batch", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32 * 6), ("stream", C.c_void_p)]
+
+
+class _HParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("eps_clip", "value_coef", "entropy_coef", "x_entropy_coef",
+                                         "entropy_multiplier", "fs_coef")]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmi355ppo.so")
+
+
+EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_param_count mi_set_params "
+           "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_put_step "
+           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_forward mi_compute_estimates "
+           "mi_adv_stats mi_adv_apply mi_minibatch mi_optimizer_step mi_loss_log_read mi_device_ptr "
+           "mi_set_multirank mi_minibatch_finish mi_op_conv3x3 mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
+
+
+def load_library():
+    """dlopen the in-tree library (built by `make -C csrc` / __graft_entry__.build())."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise EngineError(f"{path} not found: build it with `make -C train-procgen-pytorch_amd/csrc` "
+                          "(python __graft_entry__.py build).  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.mi_last_error.restype = C.c_char_p
+    lib.mi_param_count.restype = C.c_int64
+    lib.mi_host_alloc.restype = C.c_void_p
+    lib.mi_host_alloc.argtypes = [C.c_size_t]
+    lib.mi_host_free.argtypes = [C.c_void_p]
+    lib.mi_host_free.restype = None
+    _LIB = lib
+    return lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine:
+    """One device context (one GPU).  Methods mirror the C entry points one to one."""
+
+    def __init__(self, arch, n_steps, n_envs, n_actions, max_batch, obs_dim=0, mlp_depth=0, mlp_width=0, out_dim=256,
+                 device=0, stream=None):
+        self.lib = load_library()
+        self.arch = ARCH_IMPALA if arch in ("impala", ARCH_IMPALA) else ARCH_MLP
+        cfg = _Config(arch=self.arch, n_steps=n_steps, n_envs=n_envs, n_actions=n_actions, obs_dim=obs_dim,
+                      mlp_depth=mlp_depth, mlp_width=mlp_width, out_dim=out_dim, max_batch=max_batch, device=device,
+                      stream=stream)
+        self.T, self.E, self.A, self.max_batch = n_steps, n_envs, n_actions, max(max_batch, n_envs)
+        self.H = 256 if self.arch == ARCH_IMPALA else out_dim
+        self.obs_dim = obs_dim
+        self._ctx = C.c_void_p()
+        self._chk(self.lib.mi_create(C.byref(cfg), C.byref(self._ctx)))
+        self.n_params = int(self.lib.mi_param_count(self._ctx))
+        self._pinned = []
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(f"libmi355ppo error {rc}: {self.lib.mi_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            for p in self._pinned:
+                self.lib.mi_host_free(C.c_void_p(p))
+            self._pinned = []
+            self.lib.mi_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self.lib.mi_sync(self._ctx))
+
+    def pinned(self, shape, dtype):
+        """numpy array over page-locked host memory owned by this engine."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.mi_host_alloc(n)
+        if not p:
+            raise EngineError("mi_host_alloc failed")
+        self._pinned.append(p)
+        buf = (C.c_char * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    # ------------------------------------------------------------------ parameters
+    def set_params(self, flat):
+        flat = _f32(flat)
+        self._chk(self.lib.mi_set_params(self._ctx, _fp(flat), C.c_int64(flat.size)))
+
+    def get_params(self):
+        out = np.empty(self.n_params, np.float32)
+        self._chk(self.lib.mi_get_params(self._ctx, _fp(out), C.c_int64(out.size)))
+        return out
+
+    def get_grads(self):
+        out = np.empty(self.n_params, np.float32)
+        self._chk(self.lib.mi_get_grads(self._ctx, _fp(out), C.c_int64(out.size)))
+        return out
+
+    def set_adam_state(self, m, v):
+        m, v = _f32(m), _f32(v)
+        self._chk(self.lib.mi_set_adam_state(self._ctx, _fp(m), _fp(v), C.c_int64(m.size)))
+
+    def get_adam_state(self):
+        m, v = np.empty(self.n_params, np.float32), np.empty(self.n_params, np.float32)
+        self._chk(self.lib.mi_get_adam_state(self._ctx, _fp(m), _fp(v), C.c_int64(m.size)))
+        return m, v
+
+    # ------------------------------------------------------------------ rollout storage
+    def put_obs(self, t, obs):
+        want = np.uint8 if self.arch == ARCH_IMPALA else np.float32
+        obs = np.ascontiguousarray(obs, dtype=want)
+        self._chk(self.lib.mi_put_obs(self._ctx, C.c_int32(t), _fp(obs), C.c_size_t(obs.nbytes)))
+        return obs      # caller keeps it alive until the next sync
+
+    def put_step(self, t, rew, done):
+        rew, done = _f32(rew), _f32(done)
+        self._chk(self.lib.mi_put_step(self._ctx, C.c_int32(t), _fp(rew), _fp(done)))
+        return rew, done
+
+    def put_policy_outputs(self, t, act=None, logp=None, value=None):
+        act = None if act is None else np.ascontiguousarray(act, dtype=np.int32)
+        logp = None if logp is None else _f32(logp)
+        value = None if value is None else _f32(value)
+        self._chk(self.lib.mi_put_policy_outputs(self._ctx, C.c_int32(t), _fp(act), _fp(logp), _fp(value)))
+
+    def read_field(self, field):
+        n = (self.T + 1) * self.E if field == F_VALUE else self.T * self.E
+        out = np.empty(n, np.float32)
+        self._chk(self.lib.mi_read_field(self._ctx, C.c_int32(field), _fp(out), C.c_int64(n)))
+        return out.reshape(-1, self.E)
+
+    def write_field(self, field, arr):
+        arr = _f32(arr).reshape(-1)
+        self._chk(self.lib.mi_write_field(self._ctx, C.c_int32(field), _fp(arr), C.c_int64(arr.size)))
+
+    # ------------------------------------------------------------------ policy
+    def policy_step(self, t, seed=0, u=None, want_outputs=True):
+        u = None if u is None else _f32(u)
+        if not want_outputs:
+            self._chk(self.lib.mi_policy_step(self._ctx, C.c_int32(t), C.c_uint64(seed), _fp(u), None, None, None))
+            return None
+        act = np.empty(self.E, np.int64)
+        logp = np.empty(self.E, np.float32)
+        val = np.empty(self.E, np.float32)
+        self._chk(self.lib.mi_policy_step(self._ctx, C.c_int32(t), C.c_uint64(seed), _fp(u), _fp(act), _fp(logp), _fp(val)))
+        return act, logp, val
+
+    def forward(self, obs, want_feat=False):
+        want = np.uint8 if self.arch == ARCH_IMPALA else np.float32
+        obs = np.ascontiguousarray(obs, dtype=want)
+        n = obs.shape[0]
+        lp = np.empty((n, self.A), np.float32)
+        val = np.empty(n, np.float32)
+        feat = np.empty((n, self.H), np.float32) if want_feat else None
+        self._chk(self.lib.mi_forward(self._ctx, _fp(obs), C.c_int32(n), _fp(lp), _fp(val), _fp(feat)))
+        return (lp, val, feat) if want_feat else (lp, val)
+
+    # ------------------------------------------------------------------ estimates
+    def compute_estimates(self, gamma, lmbda, use_gae=True, normalize_adv=True):
+        self._chk(self.lib.mi_compute_estimates(self._ctx, C.c_float(gamma), C.c_float(lmbda), C.c_int32(int(use_gae)),
+                                                C.c_int32(int(normalize_adv))))
+
+    def adv_stats(self):
+        s = (C.c_double * 3)()
+        self._chk(self.lib.mi_adv_stats(self._ctx, s))
+        return np.array(list(s), dtype=np.float64)
+
+    def adv_apply(self, stats3):
+        s = (C.c_double * 3)(*[float(x) for x in stats3])
+        self._chk(self.lib.mi_adv_apply(self._ctx, s))
+
+    # ------------------------------------------------------------------ optimisation
+    @staticmethod
+    def hparams(eps_clip=0.2, value_coef=0.5, entropy_coef=0.01, x_entropy_coef=0.0, entropy_multiplier=1.0, fs_coef=0.0):
+        return _HParams(eps_clip, value_coef, entropy_coef, x_entropy_coef, entropy_multiplier, fs_coef)
+
+    def minibatch(self, idx, n_global, hp):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        self._chk(self.lib.mi_minibatch(self._ctx, _fp(idx), C.c_int32(idx.size), C.c_int32(n_global), C.byref(hp)))
+
+    def minibatch_finish(self):
+        self._chk(self.lib.mi_minibatch_finish(self._ctx))
+
+    def set_multirank(self, enabled):
+        self._chk(self.lib.mi_set_multirank(self._ctx, C.c_int32(int(enabled))))
+
+    def optimizer_step(self, lr, max_grad_norm, adam_step, want_norm=False):
+        g = C.c_float(0)
+        self._chk(self.lib.mi_optimizer_step(self._ctx, C.c_float(lr), C.c_float(max_grad_norm), C.c_int32(adam_step),
+                                             C.byref(g) if want_norm else None))
+        return g.value if want_norm else None
+
+    def loss_log(self, reset=True, max_records=4096):
+        out = np.empty((max_records, 8), np.float32)
+        n = C.c_int32(0)
+        self._chk(self.lib.mi_loss_log_read(self._ctx, _fp(out), C.c_int32(max_records), C.byref(n), C.c_int32(int(reset))))
+        return out[:n.value].copy()
+
+    def device_ptr(self, which):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.mi_device_ptr(self._ctx, C.c_int32(which), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # ------------------------------------------------------------------ op-level (tests)
+    def op_conv3x3(self, mode, cin, cout, hw, w_ref, inp=None, relu_in=False, bias=None, res=None, mask=None, dout=None):
+        is_u8 = inp is not None and inp.dtype == np.uint8
+        n = (inp if inp is not None else dout).shape[0]
+        inp = None if inp is None else np.ascontiguousarray(inp)
+        w_ref = _f32(w_ref)
+        bias, res, mask, dout = (None if a is None else _f32(a) for a in (bias, res, mask, dout))
+        if mode == 2:
+            out, db = np.empty((cout, cin, 3, 3), np.float32), np.empty(cout, np.float32)
+        else:
+            out, db = np.empty((n, hw, hw, cin if mode == 1 else cout), np.float32), None
+        self._chk(self.lib.mi_op_conv3x3(self._ctx, C.c_int32(mode), C.c_int32(cin), C.c_int32(cout), C.c_int32(hw),
+                                         C.c_int32(n), _fp(inp), C.c_int32(int(is_u8)), C.c_int32(int(relu_in)), _fp(w_ref),
+                                         _fp(bias), _fp(res), _fp(mask), _fp(dout), _fp(out), _fp(db)))
+        return (out, db) if mode == 2 else out
+
+    def op_maxpool(self, mode, x, dout=None):
+        x = _f32(x)
+        n, hw, _, c = x.shape
+        dout = None if dout is None else _f32(dout)
+        out = np.empty((n, hw // 2, hw // 2, c) if mode == 0 else x.shape, np.float32)
+        self._chk(self.lib.mi_op_maxpool(self._ctx, C.c_int32(mode), C.c_int32(n), C.c_int32(hw), C.c_int32(c), _fp(x),
+                                         _fp(dout), _fp(out)))
+        return out
+
+    def op_gemm(self, A, B, transpose_a=False, transpose_b=False):
+        """C = op(A) @ op(B) with the operands left in place (strided access inside the kernel)."""
+        A, B = _f32(A), _f32(B)
+        M, K = (A.shape[1], A.shape[0]) if transpose_a else A.shape
+        N = B.shape[0] if transpose_b else B.shape[1]
+        sam, sak = (1, A.shape[1]) if transpose_a else (A.shape[1], 1)
+        sbk, sbn = (1, B.shape[1]) if transpose_b else (B.shape[1], 1)
+        out = np.empty((M, N), np.float32)
+        self._chk(self.lib.mi_op_gemm(self._ctx, C.c_int32(M), C.c_int32(N), C.c_int32(K), _fp(A), C.c_int64(sam),
+                                      C.c_int64(sak), _fp(B), C.c_int64(sbk), C.c_int64(sbn), _fp(out)))
+        return out
+
+    def selftest_mfma(self):
+        e = C.c_float(0)
+        self._chk(self.lib.mi_selftest_mfma(self._ctx, C.byref(e)))
+        return e.value
