@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env steps/sec of the PPO hot path, coinrun hard-500 shape (IMPALA-CNN, T=256,
+256 envs per GPU, 3 epochs x 8 minibatches of 8192), learner side, synthetic frames resident in HBM.
+
+One "step" (--steps) = one PPO iteration = T*E env steps: T+1 policy steps on the stored frames (forward,
+sample, actions read back to the host every step, rewards/dones uploaded every step), GAE + advantage
+normalisation, then epoch x n_minibatch minibatch updates (index gather inside the first conv, forward,
+fused loss, backward, clip + Adam) -- everything agents/ppo.py:225-255 does except env.step and logging.
+
+    python bench.py                      # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W     # weak scaling: 256 envs per GPU, global minibatch 8192
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "train-procgen-pytorch_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import yaml
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: matrix fp32 (v_mfma_f32_*_f32), dense
+
+
+def cpu_baseline(T, n_samples, threads):
+    """The CPU oracle (oracle/ppo_oracle.py, a restatement of the reference's PyTorch path) timed on the host
+    cores on a bounded sample and extrapolated with the iteration's own sample counts."""
+    from oracle import ppo_oracle as O
+    from common.model import ImpalaModel
+    from common.policy import CategoricalPolicy
+    torch.set_num_threads(threads)
+    torch.manual_seed(6033)
+    pol = CategoricalPolicy(ImpalaModel(3), False, 15)
+    params = {k: v.detach().numpy().copy() for k, v in pol.state_dict().items()}
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, size=(n_samples, 64, 64, 3), dtype=np.uint8)
+    ag = O.OraclePPO(params, "impala", 1, n_samples, learning_rate=5e-4)
+    obs = O.frames_to_obs(frames)
+    f = lambda x: torch.from_numpy(x.astype(np.float32))
+    act, logp = f(rng.integers(0, 15, n_samples)), f(np.full(n_samples, np.log(1 / 15)))
+    val, ret, adv = f(rng.standard_normal(n_samples)), f(rng.standard_normal(n_samples)), f(rng.standard_normal(n_samples))
+    p = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        O.policy_forward(p, "impala", obs[:64])
+    t0 = time.time()
+    with torch.no_grad():
+        O.policy_forward(p, "impala", obs)
+    t_fwd = (time.time() - t0) / n_samples
+    t0 = time.time()
+    _, g = ag.loss_and_grads(obs, act, logp, val, ret, adv)
+    O.clip_grad_norm(g, 0.5)
+    O.adam_step(ag.p, g, ag.m, ag.v, 1, 5e-4)
+    t_train = (time.time() - t0) / n_samples
+    per_step = t_fwd * (1 + 1.0 / T) + 3 * t_train
+    return dict(value=1.0 / per_step, unit="env steps/s", cores=threads, kind="port",
+                sample=f"{n_samples}-frame rollout forward + one {n_samples}-sample fwd/bwd/clip/Adam minibatch of the CPU "
+                       f"oracle, extrapolated to (1+1/T) forwards + 3 update passes per env step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--param_name", default="hard-500")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--h2d", action="store_true", help="also upload the E frames of every rollout step from pinned host memory")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from agents.ppo import PPO
+    from common.model import ImpalaModel
+    from common.policy import CategoricalPolicy
+    from common.storage import Storage
+
+    hp = yaml.safe_load(open(os.path.join(PKG, "hyperparams", "procgen", "config.yml")))[args.param_name]
+    T, E, A = hp["n_steps"], hp["n_envs"], 15
+    torch.manual_seed(6033)
+    model = ImpalaModel(in_channels=3)
+    policy = CategoricalPolicy(model, False, A)
+    policy.device = device
+    storage = Storage((3, 64, 64), model.output_dim, T, E, device)
+
+    class _Log:
+        episode_reward_buffer = [0.0]
+        logdir = "/tmp"
+    agent = PPO(None, policy, _Log(), storage, device, 1, seed=rank, **hp)
+    eng = agent.engine
+
+    rng = np.random.default_rng(rank)
+    rew = eng.pinned((T, E), np.float32)
+    done = eng.pinned((T, E), np.float32)
+    rew[:] = rng.standard_normal((T, E))
+    done[:] = rng.random((T, E)) < 0.01
+    stage = eng.pinned((E, 64, 64, 3), np.uint8)
+    host_frames = None
+    for t in range(T + 1):
+        stage[...] = rng.integers(0, 256, size=stage.shape, dtype=np.uint8)
+        eng.put_obs(t, stage)
+        eng.sync()
+    if args.h2d:
+        host_frames = [eng.pinned((E, 64, 64, 3), np.uint8) for _ in range(4)]
+        for h in host_frames:
+            h[...] = rng.integers(0, 256, size=h.shape, dtype=np.uint8)
+
+    def iteration(it):
+        for t in range(T):
+            if host_frames is not None:
+                eng.put_obs(t, host_frames[t & 3])
+            eng.policy_step(t, seed=it)                 # returns act/logp/value to the host (env.step needs act)
+            eng.put_step(t, rew[t], done[t])
+        eng.policy_step(T, seed=it)
+        storage.compute_estimates(hp["gamma"], hp["lmbda"], hp["use_gae"], hp["normalize_adv"], agent.coll)
+        return agent.optimize()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        iteration(it)
+    eng.profile_enable(True)
+    eng.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        summary = iteration(args.warmup + it)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = eng.profile_read(reset=True)
+    eng.profile_enable(False)
+
+    if rank == 0:
+        steps_total = world * T * E * args.steps
+        value = steps_total / dt
+        upd = [r for r in prof if r["phase"] == "update" and r["kernel"].startswith("conv")]
+        dom = max(upd, key=lambda r: r["ms"]) if upd else None
+        roof = None
+        if dom is not None:
+            sec = dom["ms"] / 1e3
+            gbs, tfs = dom["bytes"] / sec / 1e9, dom["flops"] / sec / 1e12
+            f_h, f_m = gbs / HBM_PEAK_GBS, tfs / MFMA_F32_PEAK_TF
+            bound = "mfma" if f_m >= f_h else "hbm"
+            roof = dict(bound=bound, achieved=(tfs if bound == "mfma" else gbs), peak=(MFMA_F32_PEAK_TF if bound == "mfma" else HBM_PEAK_GBS),
+                        unit=("TFLOP/s" if bound == "mfma" else "GB/s"), frac=(f_m if bound == "mfma" else f_h), traffic=None,
+                        kernel=dom["kernel"], avg_launch_ms=dom["ms"] / dom["launches"], launches=dom["launches"],
+                        samples_per_launch=dom["samples"] / dom["launches"], hbm_GBps=gbs, hbm_frac=f_h, mfma_TFps=tfs, mfma_frac=f_m,
+                        share_of_timed_region=dom["ms"] / 1e3 / dt)
+        out = {"metric": "env steps/sec (whole node), coinrun hard-500 IMPALA-CNN PPO", "value": value, "unit": "env steps/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"PPO iteration, {args.param_name}: IMPALA-CNN, T={T}, E={E} envs per GPU, "
+                                      f"{hp['epoch']} epochs x {hp['n_minibatch']} minibatches of {agent.mini_batch_size} (global), "
+                                      f"A={A}, frames resident in HBM" + (" + per-step H2D" if args.h2d else ""),
+                          "parallelism": f"dp{world} over n_envs"},
+               "roofline": roof,
+               "kernels": sorted(prof, key=lambda r: -r["ms"])[:12],
+               "loss_total": summary["Loss/total"]}
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            out["cpu_baseline"] = cpu_baseline(T, args.cpu_sample, threads)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

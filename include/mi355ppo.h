@@ -65,6 +65,7 @@ int mi_get_adam_state(mi_ctx* ctx, float* exp_avg, float* exp_avg_sq, int64_t n)
 
 /* ---- rollout storage (Storage.store / store_last, common/storage.py:39-54).  t in [0, T]. */
 int mi_put_obs(mi_ctx* ctx, int32_t t, const void* obs, size_t bytes);     /* E frames uint8 NHWC, or E x obs_dim fp32 */
+int mi_get_obs(mi_ctx* ctx, int32_t t, void* obs, size_t bytes);           /* Storage.obs_batch[t] read-back */
 int mi_put_step(mi_ctx* ctx, int32_t t, const float* rew, const float* done);            /* rew/done (E,) */
 /* teacher forcing / compat path: overwrite what the policy step stored.  Any pointer may be NULL. */
 int mi_put_policy_outputs(mi_ctx* ctx, int32_t t, const int32_t* act, const float* logp, const float* value);
@@ -78,6 +79,14 @@ int mi_write_field(mi_ctx* ctx, int32_t field, const float* in, int64_t n);
  *      Host outputs may be NULL (then the call does not synchronise). */
 int mi_policy_step(mi_ctx* ctx, int32_t t, uint64_t seed, const float* u,
                    int64_t* act_out, float* logp_out, float* value_out);
+
+/* ---- PPO.predict(obs, hidden, done) on caller data (agents/ppo.py:72-81) when the caller has not said which
+ *      storage slot the observation belongs to: obs (E frames / rows) is staged on the device, forward + sample
+ *      run on it, and mi_commit_staged(t) later moves the staged observation and policy outputs into ring slot t
+ *      (what Storage.store / store_last do with the same arrays, common/storage.py:39-54) without a second PCIe trip. */
+int mi_predict_staged(mi_ctx* ctx, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
+                      int64_t* act_out, float* logp_out, float* value_out);
+int mi_commit_staged(mi_ctx* ctx, int32_t t);
 
 /* ---- stateless forward on caller data (policy(obs, hx, masks) / hidden_to_output, common/policy.py:61-87).
  *      obs: n frames uint8 NHWC or n x obs_dim fp32.  logp_all: n x A normalised log-probs
@@ -106,6 +115,15 @@ int mi_device_ptr(mi_ctx* ctx, int32_t which, void** ptr, int64_t* n_floats);
 /* two-phase loss finalisation for multi-rank runs (phase 2 after the cross-rank sum of the stats) */
 int mi_set_multirank(mi_ctx* ctx, int32_t enabled);
 int mi_minibatch_finish(mi_ctx* ctx);      /* multirank only: phase 2 + backward after the stats all-reduce */
+
+/* ---- live kernel timing for bench.py's roofline leg: HIP events recorded on the context's stream around every
+ *      conv / pool / GEMM launch.  Classes are reported separately for the rollout phase (phase 0, n = E) and the
+ *      update phase (phase 1, n = minibatch).  mi_profile_read fills up to max_rows rows of
+ *      {class id, phase, launches, total ms, total samples, total algorithmic bytes, total algorithmic flops}
+ *      (layer-boundary model of SURVEY.md 8(d)); names via mi_profile_class_name. */
+int mi_profile_enable(mi_ctx* ctx, int32_t enabled);
+int mi_profile_read(mi_ctx* ctx, double* rows7, int32_t max_rows, int32_t* n_rows, int32_t reset);
+const char* mi_profile_class_name(int32_t class_id);
 
 /* ---- op-level entry points for parity tests (host buffers in, host buffers out; NHWC fp32) */
 int mi_op_conv3x3(mi_ctx* ctx, int32_t mode /*0 fwd,1 dgrad,2 wgrad*/, int32_t cin, int32_t cout, int32_t hw, int32_t n,

@@ -237,8 +237,23 @@ def test_impala_minibatch_vs_oracle_teacher_forced():
                              torch.from_numpy(adv.reshape(-1)[idx]))
     for j, k in enumerate(("pi_loss", "value_loss", "entropy", "x_ent", "total", "fs")):
         assert abs(rec[j] - L[k]) < 1e-5 * max(1.0, abs(L[k])), (k, rec[j], L[k])
-    worst = _check_grads(flat_g, shapes, {k: v.numpy() for k, v in g.items()})
-    print("worst relative grad error", worst)
+    # fp32 autograd on the CPU is itself 2e-4..4e-4 (relative, per tensor) away from an fp64 run of the same
+    # oracle on this minibatch: single ReLU / max-pool decisions flip with the summation order and move every
+    # upstream gradient by a finite amount.  So: 5e-3 against the fp32 oracle, and -- the sharper statement --
+    # the HIP gradients are no further from the fp64 oracle than 3x the fp32 oracle's own distance.
+    _check_grads(flat_g, shapes, {k: v.numpy() for k, v in g.items()}, rtol=5e-3)
+    ag64 = O.OraclePPO(params, "impala", T, E, epoch=1, n_minibatch=1, mini_batch_size=B)
+    ag64.p = {k: v.double() for k, v in ag64.p.items()}
+    _, g64 = ag64.loss_and_grads(obs[ti].double(), torch.from_numpy(act.reshape(-1)[idx]).double(),
+                                 torch.from_numpy(logp.reshape(-1)[idx]).double(), torch.from_numpy(val[:-1].reshape(-1)[idx]).double(),
+                                 torch.from_numpy(ret.reshape(-1)[idx]).double(), torch.from_numpy(adv.reshape(-1)[idx]).double())
+    mine = layout.unflatten(shapes, flat_g)
+    for k in g:
+        r = g64[k].numpy()
+        sc = np.sqrt((r ** 2).sum()) + 1e-12
+        e_cpu = np.sqrt(((g[k].double().numpy() - r) ** 2).sum()) / sc
+        e_hip = np.sqrt(((mine[k].astype(np.float64) - r) ** 2).sum()) / sc
+        assert e_hip < 3.0 * e_cpu + 2e-5, (k, e_hip, e_cpu)
     eng.close()
 
 

@@ -1,0 +1,209 @@
+"""PPO agent (reference: agents/ppo.py:9-279) on the MI355X engine.
+
+Same constructor and public methods; what differs is where things live.  The rollout ring, the
+parameters, Adam and every intermediate of the update are device-resident; per rollout step the host
+uploads E uint8 frames (pinned, async) and downloads E actions; per minibatch it sends an index
+vector.  No ``.item()`` per minibatch: loss records are appended to a device log and read once per
+``optimize()``.  Reference quirks kept on purpose: unscaled gradient accumulation (ppo.py:170-177),
+sign-flipped 'Loss/pi' / 'Loss/v' (:178-179), ``mini_batch_size`` shrunk to T*E/n_minibatch (:108-110),
+validation rollouts that are never trained on (:241-252).
+"""
+import numpy as np
+import torch
+
+from common.misc_util import adjust_lr, adjust_lr_grok
+from common.model import as_device_obs
+from mi355.dist import Collective, DevicePointerTensor, shard_indices
+from mi355.engine import Engine, PTR_GRADS, PTR_LOSS_STATS
+from mi355.optim import DeviceAdam
+from .base_agent import BaseAgent
+
+
+class PPO(BaseAgent):
+    def __init__(self, env, policy, logger, storage, device, n_checkpoints, env_valid=None, storage_valid=None,
+                 n_steps=128, n_envs=8, epoch=3, n_minibatch=8, mini_batch_size=32 * 8, gamma=0.99, lmbda=0.95,
+                 learning_rate=2.5e-4, grad_clip_norm=0.5, eps_clip=0.2, value_coef=0.5, entropy_coef=0.01,
+                 x_entropy_coef=0., normalize_adv=True, normalize_rew=True, use_gae=True, entropy_scaling=None,
+                 increasing_lr=False, sparsity_coef=0., fs_coef=0., **kwargs):
+        super().__init__(env, policy, logger, storage, device, n_checkpoints, env_valid, storage_valid)
+        if fs_coef != 0.:
+            raise NotImplementedError("fs_coef != 0: the feature-sparsity term is reported but its gradient is not built")
+        self.fs_coef = fs_coef
+        self.total_timesteps = 0
+        self.entropy_scaling = entropy_scaling
+        self.entropy_multiplier = 1.
+        self.s_loss_coef = sparsity_coef
+        self.min_rew, self.max_rew = -1., 11.
+        self.n_steps, self.n_envs = n_steps, n_envs
+        self.epoch, self.n_minibatch, self.mini_batch_size = epoch, n_minibatch, mini_batch_size
+        self.gamma, self.lmbda = gamma, lmbda
+        self.learning_rate = learning_rate
+        self.grad_clip_norm = grad_clip_norm
+        self.eps_clip, self.value_coef, self.entropy_coef = eps_clip, value_coef, entropy_coef
+        self.x_entropy_coef = x_entropy_coef
+        self.normalize_adv, self.normalize_rew, self.use_gae = normalize_adv, normalize_rew, use_gae
+        self.adjust_lr = adjust_lr_grok if increasing_lr else adjust_lr
+        self.seed = int(kwargs.get("seed", 0))
+
+        # ---- data parallel over n_envs: this process owns n_envs envs; the global minibatch spans all ranks
+        self.coll = Collective()
+        self.n_envs_global = n_envs * self.coll.world
+        n_total = n_steps * self.n_envs_global
+        max_local = min(mini_batch_size, n_total // n_minibatch)
+        dev_index = device.index if isinstance(device, torch.device) and device.index is not None else 0
+        arch = policy.arch
+        emb = policy.embedder
+        self.engine = Engine(arch, n_steps, n_envs, policy.action_size, max_batch=max(max_local, n_envs),
+                             obs_dim=getattr(emb, "input_size", 0), mlp_depth=getattr(emb, "depth", 0),
+                             mlp_width=getattr(emb, "mid_weight", 0), out_dim=emb.output_dim, device=dev_index)
+        policy.attach_engine(self.engine)
+        storage.attach_engine(self.engine)
+        self.engine_valid = None
+        if storage_valid is not None:
+            # inference-only twin for the validation rollouts (shares nothing but the weights it is handed)
+            self.engine_valid = Engine(arch, n_steps, n_envs, policy.action_size, max_batch=n_envs,
+                                       obs_dim=getattr(emb, "input_size", 0), mlp_depth=getattr(emb, "depth", 0),
+                                       mlp_width=getattr(emb, "mid_weight", 0), out_dim=emb.output_dim, device=dev_index)
+            storage_valid.attach_engine(self.engine_valid)
+        self.optimizer = DeviceAdam(policy, self.engine, learning_rate, eps=1e-5)
+        self._grads_t = self._stats_t = None
+        if self.coll.active:
+            self.engine.set_multirank(True)
+            gp, gn = self.engine.device_ptr(PTR_GRADS)
+            sp, sn = self.engine.device_ptr(PTR_LOSS_STATS)
+            self._grads_t = DevicePointerTensor(gp, gn).tensor(dev_index)
+            self._stats_t = DevicePointerTensor(sp, sn).tensor(dev_index)
+        self._stage = [self.engine.pinned((n_envs,) + self._obs_stage_shape(arch, emb), self._obs_dtype(arch)) for _ in range(2)]
+        self._stage_i = 0
+        self._iter = 0
+
+    @staticmethod
+    def _obs_stage_shape(arch, emb):
+        return (64, 64, 3) if arch == "impala" else (emb.input_size,)
+
+    @staticmethod
+    def _obs_dtype(arch):
+        return np.uint8 if arch == "impala" else np.float32
+
+    # ------------------------------------------------------------------ predict
+    def _predict_into(self, engine, storage, t, obs):
+        """Upload obs into ring slot t (pinned double buffer), forward + sample on the device."""
+        buf = self._stage[self._stage_i]
+        self._stage_i ^= 1
+        buf[...] = as_device_obs(obs, self.policy.arch)
+        engine.put_obs(t, buf)
+        act, logp, value = engine.policy_step(t, seed=self.seed * 1000003 + self._iter)
+        storage.note_predicted(t, obs, act, logp, value)
+        return act, logp, value
+
+    def predict(self, obs, hidden_state, done):
+        """agents/ppo.py:72-81.  The observation is staged on the device; the ``Storage.store`` /
+        ``store_last`` call that follows with the same array commits it into its slot on the device, so the
+        frames cross PCIe once."""
+        self._predict_calls = getattr(self, "_predict_calls", 0) + 1
+        act, logp, value = self.engine.predict_staged(as_device_obs(obs, self.policy.arch),
+                                                      seed=self.seed * 1000003 + self._iter,
+                                                      counter=self._predict_calls * self.n_envs)
+        self.storage.note_predicted(-1, obs, act, logp, value)
+        return act, logp, value, np.asarray(hidden_state)
+
+    def predict_w_value_saliency(self, obs, hidden_state, done):
+        raise NotImplementedError("value saliency (input gradient) is a 'next' row of SURVEY 8(f), not built yet")
+
+    # ------------------------------------------------------------------ optimize
+    def _hparams(self):
+        return self.engine.hparams(self.eps_clip, self.value_coef, self.entropy_coef, self.x_entropy_coef,
+                                   self.entropy_multiplier, self.fs_coef)
+
+    def optimize(self):
+        if self.entropy_scaling == "reward_based":
+            mean_rew = np.mean(self.logger.episode_reward_buffer)
+            self.entropy_multiplier = 1 - ((mean_rew - self.min_rew) / (self.max_rew - self.min_rew))
+        elif self.entropy_scaling == "time_based":
+            self.entropy_multiplier = 1 - (self.t / self.total_timesteps)
+
+        n_total = self.n_steps * self.n_envs_global
+        batch_size = n_total // self.n_minibatch
+        if batch_size < self.mini_batch_size:
+            self.mini_batch_size = batch_size
+        grad_accumulation_steps = batch_size / self.mini_batch_size
+        cnt = 1
+        eng, coll, hp = self.engine, self.coll, self._hparams()
+        recurrent = self.policy.is_recurrent()
+        for _ in range(self.epoch):
+            for chunk in self.storage.minibatch_index_stream(self.mini_batch_size, recurrent, self.n_envs_global):
+                local = shard_indices(chunk, self.n_envs_global, coll.rank, coll.world)
+                eng.minibatch(local, len(chunk), hp)
+                if coll.active:
+                    coll.allreduce_sum_(self._stats_t)       # 32 floats: loss sums + mean action probabilities
+                    eng.minibatch_finish()
+                if cnt % grad_accumulation_steps == 0:
+                    if coll.active:
+                        coll.allreduce_sum_(self._grads_t)   # ONE collective per optimizer step: the flat gradient
+                    self.optimizer.step(self.grad_clip_norm)
+                cnt += 1
+        log = eng.loss_log(reset=True)
+        nan = float("nan")
+        fs = float(np.mean(log[:, 5])) if self.policy.arch == "impala" else nan
+        return {'Loss/pi': float(np.mean(-log[:, 0])), 'Loss/v': float(np.mean(-log[:, 1])),
+                'Loss/entropy': float(np.mean(log[:, 2])), 'Loss/x_entropy': float(np.mean(log[:, 3])),
+                'Loss/atn_entropy': nan, 'Loss/atn_entropy2': nan, 'Loss/sparsity': nan,
+                'Loss/feature_sparsity': fs, 'Loss/total': float(np.mean(log[:, 4]))}
+
+    # ------------------------------------------------------------------ rollout + train
+    def _collect(self, env, engine, storage, obs, hidden_state, done):
+        for _ in range(self.n_steps):
+            t = storage.step
+            act, logp, value = self._predict_into(engine, storage, t, obs)
+            next_obs, rew, done, info = env.step(act)
+            storage.store(obs, hidden_state, act, rew, done, info, logp, value)
+            obs = next_obs
+        _, _, last_val = self._predict_into(engine, storage, self.n_steps, obs)
+        storage.store_last(obs, hidden_state, last_val)
+        return obs, hidden_state, done
+
+    def train(self, num_timesteps):
+        self.total_timesteps = num_timesteps
+        save_every = num_timesteps // self.num_checkpoints
+        checkpoints = sorted((i + 1) * save_every for i in range(self.num_checkpoints))
+        checkpoint_cnt = 0
+        obs = self.env.reset()
+        hidden_state = np.zeros((self.n_envs, self.storage.hidden_state_size))
+        done = np.zeros(self.n_envs)
+        if self.env_valid is not None:
+            obs_v = self.env_valid.reset()
+            hidden_state_v = np.zeros((self.n_envs, self.storage.hidden_state_size))
+            done_v = np.zeros(self.n_envs)
+        steps_per_iter = self.n_steps * self.n_envs_global
+
+        while self.t < num_timesteps:
+            self._iter += 1
+            obs, hidden_state, done = self._collect(self.env, self.engine, self.storage, obs, hidden_state, done)
+            self.storage.compute_estimates(self.gamma, self.lmbda, self.use_gae, self.normalize_adv, self.coll)
+            if self.env_valid is not None:
+                self.engine_valid.set_params(self.engine.get_params())
+                obs_v, hidden_state_v, done_v = self._collect(self.env_valid, self.engine_valid, self.storage_valid,
+                                                              obs_v, hidden_state_v, done_v)
+                self.storage_valid.compute_estimates(self.gamma, self.lmbda, self.use_gae, self.normalize_adv)
+            summary = self.optimize()
+            self.t += steps_per_iter
+            rew_batch, done_batch, true_average_reward = self.storage.fetch_log_data()
+            if (done_batch > 0).any():
+                print(f"Mean Reward:{np.mean(rew_batch[done_batch > 0]):.2f}")
+            if self.storage_valid is not None:
+                rew_batch_v, done_batch_v, true_average_reward_v = self.storage_valid.fetch_log_data()
+            else:
+                rew_batch_v = done_batch_v = true_average_reward_v = None
+            self.logger.feed(rew_batch, done_batch, true_average_reward, rew_batch_v, done_batch_v, true_average_reward_v)
+            self.optimizer, lr = self.adjust_lr(self.optimizer, self.learning_rate, self.t, num_timesteps)
+            self.logger.dump(summary, lr)
+            if checkpoint_cnt < len(checkpoints) and self.t > checkpoints[checkpoint_cnt]:
+                if self.coll.rank == 0:
+                    print("Saving model.")
+                    torch.save({'model_state_dict': self.policy.state_dict(),
+                                'optimizer_state_dict': self.optimizer.state_dict()},
+                               self.logger.logdir + '/model_' + str(self.t) + '.pth')
+                checkpoint_cnt += 1
+        self.env.close()
+        if self.env_valid is not None:
+            self.env_valid.close()

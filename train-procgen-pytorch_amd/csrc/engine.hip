@@ -39,7 +39,29 @@ struct ConvLayer { ConvShape shape; int64_t w_off, b_off; int cin, cout, hw; };
 struct Block { float *C, *P0, *A1, *P1, *A2, *P2; uint8_t* PI; int cin, cout, hin; };
 struct Linear { int64_t w_off, b_off; int in, out; };
 
+// ---- live kernel timing (bench.py roofline leg)
+enum ProfClass { PC_CONV_FWD = 0, PC_CONV_DGRAD = 5, PC_CONV_WGRAD = 10, PC_POOL_FWD = 15, PC_POOL_BWD, PC_GEMM, PC_SLAB_REDUCE, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {
+    "conv_fwd_3_16_64", "conv_fwd_16_16_32", "conv_fwd_16_32_32", "conv_fwd_32_32_16", "conv_fwd_32_32_8",
+    "conv_dgrad_3_16_64(unused)", "conv_dgrad_16_16_32", "conv_dgrad_16_32_32", "conv_dgrad_32_32_16", "conv_dgrad_32_32_8",
+    "conv_wgrad_3_16_64", "conv_wgrad_16_16_32", "conv_wgrad_16_32_32", "conv_wgrad_32_32_16", "conv_wgrad_32_32_8",
+    "maxpool_fwd", "maxpool_bwd", "gemm", "slab_reduce"};
+struct ProfPending { hipEvent_t a, b; int cls, phase; long long units; double bytes, flops; };
+struct Profiler {
+    bool on = false;
+    int phase = 0;
+    std::vector<ProfPending> pend;
+    std::vector<hipEvent_t> pool;
+    double ms[2][PC_COUNT] = {};
+    long long launches[2][PC_COUNT] = {}, units[2][PC_COUNT] = {};
+    double bytes[2][PC_COUNT] = {}, flops[2][PC_COUNT] = {};
+};
+
+struct mi_ctx;
+static void prof_harvest(mi_ctx* c);
+
 struct mi_ctx {
+    Profiler prof;
     mi_config cfg;
     hipStream_t stream;
     bool own_stream;
@@ -70,6 +92,7 @@ struct mi_ctx {
     float *loss_partial, *loss_stats, *loss_log; int log_count, log_cap;
     double* sumsq; float* gnorm;
     float* d_u; float* d_lp;
+    int32_t* s_act; float *s_logp, *s_val; bool staged_valid;
     // pinned host staging
     int32_t* h_idx; float* h_f; int32_t* h_i; size_t h_f_floats;
     int multirank;
@@ -262,6 +285,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(dalloc(&c->loss_log, (size_t)c->log_cap * 8));
     HIPC(dalloc(&c->sumsq, 2)); HIPC(dalloc(&c->gnorm, 2));
     HIPC(dalloc(&c->d_u, (size_t)E));
+    HIPC(dalloc(&c->s_act, (size_t)E)); HIPC(dalloc(&c->s_logp, (size_t)E)); HIPC(dalloc(&c->s_val, (size_t)E)); c->staged_valid = false;
     HIPC(hipHostMalloc((void**)&c->h_idx, (size_t)NB * sizeof(int32_t)));
     c->h_f_floats = (size_t)4 * (E > 64 ? E : 64);
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
@@ -274,7 +298,9 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
 
 int mi_destroy(mi_ctx* c) {
     if (!c) return 0;
+    prof_harvest(c);
     hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->prof.pool) hipEventDestroy(e);
     float* fl[] = {c->params, c->grads, c->adam_m, c->adam_v, c->rew, c->done, c->logp, c->adv, c->ret, c->value, c->obsf,
                    c->feat, c->dfeat, c->hout, c->dY, c->GC, c->GP[0], c->GP[1], c->GP[2], c->slabs, c->gemm_ws, c->col_ws,
                    c->fs_scratch, c->fs_val, c->lut, c->stage_obs, c->loss_partial, c->loss_stats, c->loss_log, c->gnorm,
@@ -285,6 +311,7 @@ int mi_destroy(mi_ctx* c) {
     for (float* p : c->mlp_act) if (p) hipFree(p);
     if (c->frames) hipFree(c->frames);
     if (c->stage_frames) hipFree(c->stage_frames);
+    hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     hipHostFree(c->h_idx); hipHostFree(c->h_f); hipHostFree(c->h_i);
     gemm_set_workspace(nullptr, 0);
@@ -324,6 +351,15 @@ int mi_put_obs(mi_ctx* c, int32_t t, const void* obs, size_t bytes) {
     ARG(bytes == want, "obs byte count != E * bytes_per_env");
     char* dst = c->frames ? (char*)c->frames : (char*)c->obsf;
     HIPC(hipMemcpyAsync(dst + (size_t)t * want, obs, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int mi_get_obs(mi_ctx* c, int32_t t, void* obs, size_t bytes) {
+    ARG(c && obs, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    const size_t want = (size_t)c->E * c->obs_bytes_per_env;
+    ARG(bytes == want, "obs byte count != E * bytes_per_env");
+    const char* src = c->frames ? (const char*)c->frames : (const char*)c->obsf;
+    HIPC(hipMemcpyAsync(obs, src + (size_t)t * want, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
     return 0;
 }
 int mi_put_step(mi_ctx* c, int32_t t, const float* rew, const float* done) {
@@ -385,6 +421,60 @@ int mi_write_field(mi_ctx* c, int32_t f, const float* in, int64_t n) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------ profiler
+static hipEvent_t prof_event(mi_ctx* c) {
+    hipEvent_t e;
+    if (!c->prof.pool.empty()) { e = c->prof.pool.back(); c->prof.pool.pop_back(); return e; }
+    hipEventCreate(&e);
+    return e;
+}
+static void prof_harvest(mi_ctx* c) {
+    if (c->prof.pend.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof.pend) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, p.a, p.b);
+        c->prof.ms[p.phase][p.cls] += ms; c->prof.launches[p.phase][p.cls]++; c->prof.units[p.phase][p.cls] += p.units;
+        c->prof.bytes[p.phase][p.cls] += p.bytes; c->prof.flops[p.phase][p.cls] += p.flops;
+        c->prof.pool.push_back(p.a); c->prof.pool.push_back(p.b);
+    }
+    c->prof.pend.clear();
+}
+struct ProfScope {
+    mi_ctx* c; ProfPending p; bool live;
+    // bytes / flops: ALGORITHMIC figures of this launch (layer-boundary model)
+    ProfScope(mi_ctx* c_, int cls, long long units, double bytes, double flops) : c(c_), live(c_->prof.on) {
+        if (!live) return;
+        p.a = prof_event(c); p.b = prof_event(c); p.cls = cls; p.phase = c->prof.phase; p.units = units; p.bytes = bytes; p.flops = flops;
+        hipEventRecord(p.a, c->stream);
+    }
+    ~ProfScope() {
+        if (!live) return;
+        hipEventRecord(p.b, c->stream);
+        c->prof.pend.push_back(p);
+        if (c->prof.pend.size() >= 4096) prof_harvest(c);
+    }
+};
+int mi_profile_enable(mi_ctx* c, int32_t enabled) { ARG(c, "null"); if (!enabled) prof_harvest(c); c->prof.on = enabled != 0; return 0; }
+const char* mi_profile_class_name(int32_t id) { return (id >= 0 && id < PC_COUNT) ? kProfNames[id] : ""; }
+int mi_profile_read(mi_ctx* c, double* rows, int32_t max_rows, int32_t* n_rows, int32_t reset) {
+    ARG(c && rows && n_rows, "null");
+    prof_harvest(c);
+    int n = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int k = 0; k < PC_COUNT; ++k)
+            if (c->prof.launches[ph][k] > 0 && n < max_rows) {
+                double* r = rows + (size_t)n * 7;
+                r[0] = k; r[1] = ph; r[2] = (double)c->prof.launches[ph][k]; r[3] = c->prof.ms[ph][k]; r[4] = (double)c->prof.units[ph][k];
+                r[5] = c->prof.bytes[ph][k]; r[6] = c->prof.flops[ph][k];
+                ++n;
+            }
+    *n_rows = n;
+    if (reset) { memset(c->prof.ms, 0, sizeof(c->prof.ms)); memset(c->prof.launches, 0, sizeof(c->prof.launches)); memset(c->prof.units, 0, sizeof(c->prof.units));
+                 memset(c->prof.bytes, 0, sizeof(c->prof.bytes)); memset(c->prof.flops, 0, sizeof(c->prof.flops)); }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ network program
 struct InputSrc { const void* base; const int32_t* idx; long long first; };   // frames or obs rows
 
@@ -393,12 +483,16 @@ static void conv_fwd(mi_ctx* c, const ConvLayer& L, const void* in, const InputS
     a.in = src ? src->base : in; a.idx = src ? src->idx : nullptr; a.in_base = src ? src->first : 0;
     a.w = c->params + L.w_off; a.bias = c->params + L.b_off; a.res = res; a.mask = nullptr; a.out = out;
     a.lut = c->lut; a.n = n; a.relu_in = relu_in;
+    const double px = (double)n * L.hw * L.hw;
+    ProfScope ps(c, PC_CONV_FWD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : 4.0 * L.cin) + 4.0 * L.cout * (res ? 2 : 1)), px * 18.0 * L.cin * L.cout);
     launch_conv_fwd(L.shape, a, c->stream);
 }
 static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const float* mask, const float* res, float* din, int n) {
     ConvArgs a{};
     a.in = dout; a.w = c->params + L.w_off; a.bias = nullptr; a.res = res; a.mask = mask; a.out = din;
     a.lut = c->lut; a.n = n; a.relu_in = 0;
+    const double px = (double)n * L.hw * L.hw;
+    ProfScope ps(c, PC_CONV_DGRAD + (int)L.shape, n, px * 4.0 * (L.cout + L.cin * (1 + (mask ? 1 : 0) + (res ? 1 : 0))), px * 18.0 * L.cin * L.cout);
     launch_conv_dgrad(L.shape, a, c->stream);
 }
 static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const InputSrc* src, int relu_in, const float* dout, int n) {
@@ -407,8 +501,11 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
     a.dout = dout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in;
     const int grid = wgrad_grid(L.shape, n);
     if (grid < 1) return;
-    launch_conv_wgrad(L.shape, a, c->stream);
+    const double px = (double)n * L.hw * L.hw;
+    { ProfScope ps(c, PC_CONV_WGRAD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : 4.0 * L.cin) + 4.0 * L.cout), px * 18.0 * L.cin * L.cout);
+      launch_conv_wgrad(L.shape, a, c->stream); }
     const int wlen = L.cout * 9 * L.cin;
+    ProfScope ps(c, PC_SLAB_REDUCE, n, 4.0 * grid * (wlen + L.cout), 0.0);
     launch_reduce_slabs(c->slabs, grid, wlen + L.cout, c->grads + L.w_off, wlen, c->grads + L.b_off, L.cout, c->stream);
 }
 
@@ -417,6 +514,7 @@ static void linear_fwd(mi_ctx* c, const float* X, int relu_x, const float* W, co
     g.A = X; g.B = W; g.C = Y; g.M = n; g.N = out; g.K = in;
     g.sam = in; g.sak = 1; g.sbk = 1; g.sbn = in; g.ldc = out;
     g.bias = b; g.relu_a = relu_x; g.relu_out = relu_out;
+    ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * in + (double)in * out + (double)n * out), 2.0 * n * in * out);
     launch_gemm(g, c->stream);
 }
 // dX = dY W  (* mask > 0)
@@ -424,6 +522,7 @@ static void linear_dgrad(mi_ctx* c, const float* dY, const float* W, const float
     GemmArgs g{};
     g.A = dY; g.B = W; g.C = dX; g.M = n; g.N = in; g.K = out;
     g.sam = out; g.sak = 1; g.sbk = in; g.sbn = 1; g.ldc = in; g.mask = mask;
+    ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * out + (double)in * out + (double)n * in * (mask ? 2 : 1)), 2.0 * n * in * out);
     launch_gemm(g, c->stream);
 }
 // gW += dY^T relu?(X) ; gb += colsum(dY)
@@ -431,6 +530,7 @@ static void linear_wgrad(mi_ctx* c, const float* dY, const float* X, int relu_x,
     GemmArgs g{};
     g.A = dY; g.B = X; g.C = gW; g.M = out; g.N = in; g.K = n;
     g.sam = 1; g.sak = out; g.sbk = in; g.sbn = 1; g.ldc = in; g.relu_b = relu_x; g.accumulate = 1;
+    ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * out + (double)n * in + (double)in * out), 2.0 * n * in * out);
     launch_gemm(g, c->stream);
     launch_colsum_acc(dY, n, out, out, gb, c->stream);
 }
@@ -443,7 +543,7 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n) {
             const ConvLayer* L = &c->convs[b * 5];
             if (b == 0) conv_fwd(c, L[0], nullptr, &src, 0, nullptr, k.C, n);
             else conv_fwd(c, L[0], prev, nullptr, 0, nullptr, k.C, n);
-            launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream);
+            { ProfScope ps(c, PC_POOL_FWD, n, (double)n * k.hin * k.hin * k.cout * (4.0 + 1.25), 0.0); launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); }
             conv_fwd(c, L[1], k.P0, nullptr, 1, nullptr, k.A1, n);
             conv_fwd(c, L[2], k.A1, nullptr, 1, k.P0, k.P1, n);
             conv_fwd(c, L[3], k.P1, nullptr, 1, nullptr, k.A2, n);
@@ -498,7 +598,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         conv_wgrad(c, L[1], k.P0, nullptr, 1, Ga, n);
         conv_dgrad(c, L[1], Ga, k.P0, Gb, Gout, n);
         // max pool, then the block's first conv
-        launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream);
+        { ProfScope ps(c, PC_POOL_BWD, n, (double)n * k.hin * k.hin * k.cout * (4.0 + 1.25), 0.0); launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); }
         if (b == 0) conv_wgrad(c, L[0], nullptr, &src, 0, c->GC, n);
         else {
             conv_wgrad(c, L[0], c->blk[b - 1].P2, nullptr, 0, c->GC, n);
@@ -514,6 +614,7 @@ int mi_policy_step(mi_ctx* c, int32_t t, uint64_t seed, const float* u, int64_t*
     InputSrc src{c->frames ? (const void*)c->frames : (const void*)c->obsf, nullptr, (long long)t * E};
     const float* du = nullptr;
     if (u) { HIPC(hipMemcpyAsync(c->d_u, u, (size_t)E * 4, hipMemcpyHostToDevice, c->stream)); du = c->d_u; }
+    c->prof.phase = 0;
     net_forward(c, src, E);
     const bool last = (t == c->T);
     launch_sample(c->hout, E, c->A, du, seed, (unsigned long long)t * E, last ? nullptr : c->act + (size_t)t * E,
@@ -530,8 +631,47 @@ int mi_policy_step(mi_ctx* c, int32_t t, uint64_t seed, const float* u, int64_t*
     return 0;
 }
 
+int mi_predict_staged(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
+                      int64_t* act_out, float* logp_out, float* value_out) {
+    ARG(c && obs, "null");
+    const int E = c->E;
+    ARG(bytes == (size_t)E * c->obs_bytes_per_env, "obs byte count != E * bytes_per_env");
+    void* stage = c->stage_frames ? (void*)c->stage_frames : (void*)c->stage_obs;
+    HIPC(hipMemcpyAsync(stage, obs, bytes, hipMemcpyHostToDevice, c->stream));
+    const float* du = nullptr;
+    if (u) { HIPC(hipMemcpyAsync(c->d_u, u, (size_t)E * 4, hipMemcpyHostToDevice, c->stream)); du = c->d_u; }
+    InputSrc src{stage, nullptr, 0};
+    net_forward(c, src, E);
+    launch_sample(c->hout, E, c->A, du, seed, counter, c->s_act, c->s_logp, c->s_val, c->stream);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(c->h_i, c->s_act, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(c->h_f, c->s_logp, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(c->h_f + E, c->s_val, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    c->staged_valid = true;
+    if (act_out) for (int e = 0; e < E; ++e) act_out[e] = c->h_i[e];
+    if (logp_out) memcpy(logp_out, c->h_f, (size_t)E * 4);
+    if (value_out) memcpy(value_out, c->h_f + E, (size_t)E * 4);
+    return 0;
+}
+
+int mi_commit_staged(mi_ctx* c, int32_t t) {
+    ARG(c, "null"); ARG(t >= 0 && t <= c->T, "t out of range"); ARG(c->staged_valid, "nothing staged: call mi_predict_staged first");
+    const size_t E = c->E, ob = E * c->obs_bytes_per_env;
+    char* ring = c->frames ? (char*)c->frames : (char*)c->obsf;
+    const void* stage = c->stage_frames ? (const void*)c->stage_frames : (const void*)c->stage_obs;
+    HIPC(hipMemcpyAsync(ring + (size_t)t * ob, stage, ob, hipMemcpyDeviceToDevice, c->stream));
+    if (t < c->T) {
+        HIPC(hipMemcpyAsync(c->act + t * E, c->s_act, E * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(hipMemcpyAsync(c->logp + t * E, c->s_logp, E * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPC(hipMemcpyAsync(c->value + t * E, c->s_val, E * 4, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
 int mi_forward(mi_ctx* c, const void* obs, int32_t n, float* logp_all, float* value, float* feat) {
     ARG(c && obs, "null"); ARG(n >= 1 && n <= c->NB, "n must be in [1, max_batch]");
+    c->staged_valid = false;
     void* stage = c->stage_frames ? (void*)c->stage_frames : (void*)c->stage_obs;
     HIPC(hipMemcpyAsync(stage, obs, (size_t)n * c->obs_bytes_per_env, hipMemcpyHostToDevice, c->stream));
     InputSrc src{stage, nullptr, 0};
@@ -588,6 +728,7 @@ int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, con
     for (int k = 0; k < n; ++k) { ARG(idx[k] >= 0 && idx[k] < TE, "minibatch index out of range"); c->h_idx[k] = (int32_t)idx[k]; }
     if (n) HIPC(hipMemcpyAsync(c->d_idx, c->h_idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     InputSrc src = minibatch_src(c);
+    c->prof.phase = 1;
     net_forward(c, src, n);
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
     if (impala) launch_fs_metric(c->blk[2].P2, n, 2048, c->fs_scratch, c->fs_val, c->stream);

@@ -1,0 +1,84 @@
+"""Data-parallel plumbing: the n_envs dimension is sharded over ranks (one process per GPU).
+
+Every rank draws the SAME torch.randperm(N_global) (same seed, same stream position), forms the same
+global minibatches as the single-process reference (common/storage.py:86-91) and keeps the indices
+whose env falls in its shard.  Means are taken over the global minibatch (each rank scales its
+partial sums by 1/B_global); gradients are summed with ONE all-reduce of the flat gradient buffer per
+optimizer step (RCCL over xGMI via torch.distributed backend "nccl"; "gloo" in the CPU tests)."""
+import numpy as np
+
+
+def env_range(n_envs_global, rank, world):
+    if n_envs_global % world != 0:
+        raise ValueError(f"n_envs={n_envs_global} is not divisible by world_size={world}")
+    per = n_envs_global // world
+    return rank * per, (rank + 1) * per
+
+
+def shard_indices(chunk, n_envs_global, rank, world):
+    """Global flat indices i = t*E + e of one minibatch -> this rank's LOCAL flat indices
+    t*E_local + (e - e0), in the order they appear in the chunk."""
+    chunk = np.asarray(chunk, dtype=np.int64)
+    if world == 1:
+        return chunk
+    e0, e1 = env_range(n_envs_global, rank, world)
+    t, e = chunk // n_envs_global, chunk % n_envs_global
+    keep = (e >= e0) & (e < e1)
+    return t[keep] * (e1 - e0) + (e[keep] - e0)
+
+
+def merge_adv_stats(stats_list):
+    """Chan et al. parallel merge of per-rank {count, mean, M2} (fp64) -> global triple, from which
+    mean and the unbiased std of common/storage.py:79 follow."""
+    n, mean, m2 = 0.0, 0.0, 0.0
+    for c, mu, s in stats_list:
+        if c == 0:
+            continue
+        tot = n + c
+        d = mu - mean
+        mean = mean + d * c / tot
+        m2 = m2 + s + d * d * n * c / tot
+        n = tot
+    return np.array([n, mean, m2], dtype=np.float64)
+
+
+class Collective:
+    """Minimal wrapper so that the agent code is identical for 1 rank, gloo (CPU tensors in tests) and
+    nccl/RCCL (device tensors wrapping the engine's buffers)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as td
+        self.td = td
+        self.active = td.is_available() and td.is_initialized() and td.get_world_size(group) > 1
+        self.group = group
+        self.rank = td.get_rank(group) if self.active else 0
+        self.world = td.get_world_size(group) if self.active else 1
+
+    def allreduce_sum_(self, tensor):
+        if self.active:
+            self.td.all_reduce(tensor, op=self.td.ReduceOp.SUM, group=self.group)
+        return tensor
+
+    def allgather_f64(self, vec):
+        import torch
+        if not self.active:
+            return [np.asarray(vec, dtype=np.float64)]
+        t = torch.as_tensor(np.asarray(vec, dtype=np.float64))
+        dev = torch.device("cuda") if self.td.get_backend(self.group) == "nccl" else torch.device("cpu")
+        t = t.to(dev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.td.all_gather(out, t, group=self.group)
+        return [o.cpu().numpy() for o in out]
+
+
+class DevicePointerTensor:
+    """torch view of a raw device buffer owned by the engine (for RCCL all-reduce through
+    torch.distributed): exposes __cuda_array_interface__ and lets torch.as_tensor alias it."""
+
+    def __init__(self, ptr, n_floats):
+        self.__cuda_array_interface__ = {"shape": (int(n_floats),), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+    def tensor(self, device_index=0):
+        import torch
+        return torch.as_tensor(self, device=torch.device("cuda", device_index))

@@ -37,10 +37,10 @@ def lib_path():
 
 
 EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_param_count mi_set_params "
-           "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_put_step "
-           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_forward mi_compute_estimates "
+           "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
+           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_predict_staged mi_commit_staged mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_optimizer_step mi_loss_log_read mi_device_ptr "
-           "mi_set_multirank mi_minibatch_finish mi_op_conv3x3 mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
+           "mi_set_multirank mi_minibatch_finish mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
 
 
 def load_library():
@@ -59,6 +59,7 @@ def load_library():
     lib.mi_host_alloc.argtypes = [C.c_size_t]
     lib.mi_host_free.argtypes = [C.c_void_p]
     lib.mi_host_free.restype = None
+    lib.mi_profile_class_name.restype = C.c_char_p
     _LIB = lib
     return lib
 
@@ -152,6 +153,14 @@ class Engine:
         self._chk(self.lib.mi_put_obs(self._ctx, C.c_int32(t), _fp(obs), C.c_size_t(obs.nbytes)))
         return obs      # caller keeps it alive until the next sync
 
+    def get_obs(self, t):
+        if self.arch == ARCH_IMPALA:
+            out = np.empty((self.E, 64, 64, 3), np.uint8)
+        else:
+            out = np.empty((self.E, self.obs_dim), np.float32)
+        self._chk(self.lib.mi_get_obs(self._ctx, C.c_int32(t), _fp(out), C.c_size_t(out.nbytes)))
+        return out
+
     def put_step(self, t, rew, done):
         rew, done = _f32(rew), _f32(done)
         self._chk(self.lib.mi_put_step(self._ctx, C.c_int32(t), _fp(rew), _fp(done)))
@@ -184,6 +193,18 @@ class Engine:
         val = np.empty(self.E, np.float32)
         self._chk(self.lib.mi_policy_step(self._ctx, C.c_int32(t), C.c_uint64(seed), _fp(u), _fp(act), _fp(logp), _fp(val)))
         return act, logp, val
+
+    def predict_staged(self, obs, seed=0, counter=0, u=None):
+        want = np.uint8 if self.arch == ARCH_IMPALA else np.float32
+        obs = np.ascontiguousarray(obs, dtype=want)
+        u = None if u is None else _f32(u)
+        act, logp, val = np.empty(self.E, np.int64), np.empty(self.E, np.float32), np.empty(self.E, np.float32)
+        self._chk(self.lib.mi_predict_staged(self._ctx, _fp(obs), C.c_size_t(obs.nbytes), C.c_uint64(seed),
+                                             C.c_uint64(counter), _fp(u), _fp(act), _fp(logp), _fp(val)))
+        return act, logp, val
+
+    def commit_staged(self, t):
+        self._chk(self.lib.mi_commit_staged(self._ctx, C.c_int32(t)))
 
     def forward(self, obs, want_feat=False):
         want = np.uint8 if self.arch == ARCH_IMPALA else np.float32
@@ -240,6 +261,20 @@ class Engine:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.lib.mi_device_ptr(self._ctx, C.c_int32(which), C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    # ------------------------------------------------------------------ live kernel timing
+    def profile_enable(self, on=True):
+        self._chk(self.lib.mi_profile_enable(self._ctx, C.c_int32(int(on))))
+
+    def profile_read(self, reset=True):
+        rows = np.zeros((64, 7), np.float64)
+        n = C.c_int32(0)
+        self._chk(self.lib.mi_profile_read(self._ctx, _fp(rows), C.c_int32(64), C.byref(n), C.c_int32(int(reset))))
+        out = []
+        for r in rows[:n.value]:
+            out.append(dict(kernel=self.lib.mi_profile_class_name(C.c_int32(int(r[0]))).decode(), phase="rollout" if r[1] == 0 else "update",
+                            launches=int(r[2]), ms=float(r[3]), samples=int(r[4]), bytes=float(r[5]), flops=float(r[6])))
+        return out
 
     # ------------------------------------------------------------------ op-level (tests)
     def op_conv3x3(self, mode, cin, cout, hw, w_ref, inp=None, relu_in=False, bias=None, res=None, mask=None, dout=None):
