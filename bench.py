@@ -66,6 +66,22 @@ def cpu_baseline(T, n_samples, threads):
                        f"oracle, extrapolated to (1+1/T) forwards + 3 update passes per env step")
 
 
+def host_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a 1-GPU box exposes all
+    host CPUs but grants a 16-core share); oversubscribing the quota makes the CPU leg slower, not faster."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return min(n, 16)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +90,7 @@ def main():
     ap.add_argument("--param_name", default="hard-500")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--h2d", action="store_true", help="also upload the E frames of every rollout step from pinned host memory")
     args = ap.parse_args()
 
@@ -184,12 +201,7 @@ def main():
                "kernels": sorted(prof, key=lambda r: -r["ms"])[:12],
                "loss_total": summary["Loss/total"]}
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
-            try:
-                threads = len(os.sched_getaffinity(0))
-            except Exception:
-                pass
-            out["cpu_baseline"] = cpu_baseline(T, args.cpu_sample, threads)
+            out["cpu_baseline"] = cpu_baseline(T, args.cpu_sample, args.cpu_threads or host_cores())
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -53,9 +53,13 @@ class PPO(BaseAgent):
         dev_index = device.index if isinstance(device, torch.device) and device.index is not None else 0
         arch = policy.arch
         emb = policy.embedder
+        # with >1 rank the engine issues on a torch-owned stream, so that torch.distributed collectives on the
+        # aliased gradient buffer are ordered against the kernels that produce / consume it
+        self._tstream = torch.cuda.Stream(device=dev_index) if self.coll.active else None
         self.engine = Engine(arch, n_steps, n_envs, policy.action_size, max_batch=max(max_local, n_envs),
                              obs_dim=getattr(emb, "input_size", 0), mlp_depth=getattr(emb, "depth", 0),
-                             mlp_width=getattr(emb, "mid_weight", 0), out_dim=emb.output_dim, device=dev_index)
+                             mlp_width=getattr(emb, "mid_weight", 0), out_dim=emb.output_dim, device=dev_index,
+                             stream=self._tstream.cuda_stream if self._tstream is not None else None)
         policy.attach_engine(self.engine)
         storage.attach_engine(self.engine)
         self.engine_valid = None
@@ -135,11 +139,13 @@ class PPO(BaseAgent):
                 local = shard_indices(chunk, self.n_envs_global, coll.rank, coll.world)
                 eng.minibatch(local, len(chunk), hp)
                 if coll.active:
-                    coll.allreduce_sum_(self._stats_t)       # 32 floats: loss sums + mean action probabilities
+                    with torch.cuda.stream(self._tstream):
+                        coll.allreduce_sum_(self._stats_t)   # 32 floats: loss sums + mean action probabilities
                     eng.minibatch_finish()
                 if cnt % grad_accumulation_steps == 0:
                     if coll.active:
-                        coll.allreduce_sum_(self._grads_t)   # ONE collective per optimizer step: the flat gradient
+                        with torch.cuda.stream(self._tstream):
+                            coll.allreduce_sum_(self._grads_t)   # ONE collective per optimizer step: the flat gradient
                     self.optimizer.step(self.grad_clip_norm)
                 cnt += 1
         log = eng.loss_log(reset=True)

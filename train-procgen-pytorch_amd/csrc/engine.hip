@@ -94,7 +94,10 @@ struct mi_ctx {
     float* d_u; float* d_lp;
     int32_t* s_act; float *s_logp, *s_val; bool staged_valid;
     // pinned host staging
-    int32_t* h_idx; float* h_f; int32_t* h_i; size_t h_f_floats;
+    // index staging ring: a slot is rewritten only after the H2D copy that read it has completed
+    static constexpr int IDX_RING = 8;
+    int32_t* h_idx_ring[IDX_RING]; hipEvent_t idx_ev[IDX_RING]; bool idx_used[IDX_RING]; int idx_next;
+    float* h_f; int32_t* h_i; size_t h_f_floats;
     int multirank;
     LossArgs pending; int pending_n;
 };
@@ -286,7 +289,12 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(dalloc(&c->sumsq, 2)); HIPC(dalloc(&c->gnorm, 2));
     HIPC(dalloc(&c->d_u, (size_t)E));
     HIPC(dalloc(&c->s_act, (size_t)E)); HIPC(dalloc(&c->s_logp, (size_t)E)); HIPC(dalloc(&c->s_val, (size_t)E)); c->staged_valid = false;
-    HIPC(hipHostMalloc((void**)&c->h_idx, (size_t)NB * sizeof(int32_t)));
+    for (int k = 0; k < mi_ctx::IDX_RING; ++k) {
+        HIPC(hipHostMalloc((void**)&c->h_idx_ring[k], (size_t)NB * sizeof(int32_t)));
+        HIPC(hipEventCreateWithFlags(&c->idx_ev[k], hipEventDisableTiming));
+        c->idx_used[k] = false;
+    }
+    c->idx_next = 0;
     c->h_f_floats = (size_t)4 * (E > 64 ? E : 64);
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
@@ -313,7 +321,8 @@ int mi_destroy(mi_ctx* c) {
     if (c->stage_frames) hipFree(c->stage_frames);
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
-    hipHostFree(c->h_idx); hipHostFree(c->h_f); hipHostFree(c->h_i);
+    for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
+    hipHostFree(c->h_f); hipHostFree(c->h_i);
     gemm_set_workspace(nullptr, 0);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -725,8 +734,17 @@ int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, con
     ARG(c->log_count < c->log_cap, "loss log full: call mi_loss_log_read(reset=1)");
     ARG(c->pending_n < 0, "previous multirank minibatch not finished");
     const int64_t TE = (int64_t)c->T * c->E;
-    for (int k = 0; k < n; ++k) { ARG(idx[k] >= 0 && idx[k] < TE, "minibatch index out of range"); c->h_idx[k] = (int32_t)idx[k]; }
-    if (n) HIPC(hipMemcpyAsync(c->d_idx, c->h_idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < n; ++k) ARG(idx[k] >= 0 && idx[k] < TE, "minibatch index out of range");
+    if (n) {
+        const int slot = c->idx_next;
+        c->idx_next = (slot + 1) % mi_ctx::IDX_RING;
+        if (c->idx_used[slot]) HIPC(hipEventSynchronize(c->idx_ev[slot]));     // the DMA that read this slot is done
+        int32_t* h = c->h_idx_ring[slot];
+        for (int k = 0; k < n; ++k) h[k] = (int32_t)idx[k];
+        HIPC(hipMemcpyAsync(c->d_idx, h, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPC(hipEventRecord(c->idx_ev[slot], c->stream));
+        c->idx_used[slot] = true;
+    }
     InputSrc src = minibatch_src(c);
     c->prof.phase = 1;
     net_forward(c, src, n);
