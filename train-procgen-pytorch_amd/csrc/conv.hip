@@ -44,36 +44,100 @@ struct FwdCfg {
     static_assert(NIMG == 1 || (TH == HW && TW == HW), "multi-image work items hold whole images");
 };
 
+// Input-tile staging is split in two so that the HBM latency of tile i+1 hides under the MFMAs of tile i
+// (issue-early / write-late): tile_load puts the next tile's global loads in flight into registers before the
+// compute phase, tile_store converts (uint8 -> fp32 table / ReLU) and writes them to LDS after it.
 template <class C>
-__device__ __forceinline__ void stage_input_tile(float* s_in, const void* in, const int32_t* idx, long long in_base,
-                                                 const float* lut, int n_img, int relu_in, int img0, int ty0, int tx0) {
+struct TileRegs {
+    static constexpr int C4 = C::CINP / 4;
+    // fp32: 16-byte chunks of the haloed tile;  uint8: the tile's full-width rows as dwords (HW*3/4 per row)
+    static constexpr int ROW_DW = C::HW * 3 / 4;
+    static constexpr int N = C::IN_U8 ? (C::NIMG * C::PH * ROW_DW + 255) / 256 : (C::NPIX * C4 + 255) / 256;
+    f32x4 v[C::IN_U8 ? 1 : N];
+    uint32_t w[C::IN_U8 ? N : 1];
+};
+
+template <class C>
+__device__ __forceinline__ void tile_load(TileRegs<C>& r, const void* in, const int32_t* idx, long long in_base,
+                                          int n_img, int img0, int ty0, int tx0) {
     const int tid = threadIdx.x;
     if constexpr (C::IN_U8) {
-        for (int pix = tid; pix < C::NPIX; pix += 256) {
-            const int img = pix / (C::PH * C::PW), r = pix % (C::PH * C::PW);
-            const int gy = ty0 + r / C::PW - 1, gx = tx0 + r % C::PW - 1, n = img0 + img;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < n_img && gy >= 0 && gy < C::HW && gx >= 0 && gx < C::HW) {
-                const long long frame = idx ? (long long)idx[n] : in_base + n;
-                const uint8_t* f = (const uint8_t*)in + frame * (C::HW * C::HW * 3) + (gy * C::HW + gx) * 3;
-                v.x = lut[f[0]]; v.y = lut[f[1]]; v.z = lut[f[2]];
+        static_assert(!C::IN_U8 || C::TW == C::HW, "uint8 tiles span the full frame width");
+        constexpr int RD = TileRegs<C>::ROW_DW;
+#pragma unroll
+        for (int k = 0; k < TileRegs<C>::N; ++k) {
+            const int e = tid + k * 256;
+            uint32_t v = 0u;
+            if (e < C::NIMG * C::PH * RD) {
+                const int row = e / RD, dw = e % RD, img = row / C::PH, gy = ty0 + (row % C::PH) - 1, n = img0 + img;
+                if (n < n_img && gy >= 0 && gy < C::HW) {
+                    const long long frame = idx ? (long long)idx[n] : in_base + n;
+                    v = *(const uint32_t*)((const uint8_t*)in + frame * (C::HW * C::HW * 3) + gy * (C::HW * 3) + dw * 4);
+                }
             }
-            *(f32x4*)(s_in + pix * C::S) = v;
+            r.w[k] = v;
         }
     } else {
-        constexpr int C4 = C::CINP / 4;
-        for (int e = tid; e < C::NPIX * C4; e += 256) {
-            const int pix = e / C4, c4 = e % C4;
-            const int img = pix / (C::PH * C::PW), r = pix % (C::PH * C::PW);
-            const int gy = ty0 + r / C::PW - 1, gx = tx0 + r % C::PW - 1, n = img0 + img;
+        constexpr int C4 = TileRegs<C>::C4;
+#pragma unroll
+        for (int k = 0; k < TileRegs<C>::N; ++k) {
+            const int e = tid + k * 256;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < n_img && gy >= 0 && gy < C::HW && gx >= 0 && gx < C::HW) {
-                v = *(const f32x4*)((const float*)in + (((long long)n * C::HW + gy) * C::HW + gx) * C::CIN + c4 * 4);
-                if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (e < C::NPIX * C4) {
+                const int pix = e / C4, c4 = e % C4;
+                const int img = pix / (C::PH * C::PW), q = pix % (C::PH * C::PW);
+                const int gy = ty0 + q / C::PW - 1, gx = tx0 + q % C::PW - 1, n = img0 + img;
+                if (n < n_img && gy >= 0 && gy < C::HW && gx >= 0 && gx < C::HW)
+                    v = *(const f32x4*)((const float*)in + (((long long)n * C::HW + gy) * C::HW + gx) * C::CIN + c4 * 4);
             }
-            *(f32x4*)(s_in + pix * C::S + c4 * 4) = v;
+            r.v[k] = v;
         }
     }
+}
+
+template <class C>
+__device__ __forceinline__ void tile_store(const TileRegs<C>& r, float* s_in, const float* lut, int relu_in) {
+    const int tid = threadIdx.x;
+    if constexpr (C::IN_U8) {
+        constexpr int RD = TileRegs<C>::ROW_DW;
+#pragma unroll
+        for (int k = 0; k < TileRegs<C>::N; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::NIMG * C::PH * RD) {
+                const int row = e / RD, dw = e % RD;
+                const uint32_t v = r.w[k];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int byte = dw * 4 + b, px = byte / 3, ch = byte % 3;
+                    s_in[(row * C::PW + 1 + px) * C::S + ch] = lut[(v >> (8 * b)) & 0xffu];    // lut[0] == 0: padded rows
+                }
+            }
+        }
+    } else {
+        constexpr int C4 = TileRegs<C>::C4;
+#pragma unroll
+        for (int k = 0; k < TileRegs<C>::N; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::NPIX * C4) {
+                f32x4 v = r.v[k];
+                if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *(f32x4*)(s_in + (e / C4) * C::S + (e % C4) * 4) = v;
+            }
+        }
+    }
+}
+
+// uint8 tiles: the halo columns x = -1 / x = HW and the 4th (pad) channel are never written by tile_store
+template <class C>
+__device__ __forceinline__ void tile_clear(float* s_in) {
+    if constexpr (C::IN_U8)
+        for (int e = threadIdx.x; e < C::IN_FLOATS; e += 256) s_in[e] = 0.f;
+}
+
+template <class C>
+__device__ __forceinline__ void work_coords(int work, int& img0, int& ty0, int& tx0) {
+    if (C::NIMG > 1) { img0 = work * C::NIMG; ty0 = 0; tx0 = 0; }
+    else { img0 = work / C::TPI; const int t = work % C::TPI; ty0 = (t / C::TPI_X) * C::TH; tx0 = (t % C::TPI_X) * C::TW; }
 }
 
 template <class C>
@@ -93,13 +157,23 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     }
 
     const int nwork = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
+    tile_clear<C>(s_in);
+    TileRegs<C> regs;
+    int img0, ty0, tx0;
+    if ((int)blockIdx.x < nwork) {
+        work_coords<C>(blockIdx.x, img0, ty0, tx0);
+        tile_load<C>(regs, a.in, a.idx, a.in_base, a.n, img0, ty0, tx0);
+    }
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
-        int img0, ty0, tx0;
-        if (C::NIMG > 1) { img0 = work * C::NIMG; ty0 = 0; tx0 = 0; }
-        else { img0 = work / C::TPI; const int t = work % C::TPI; ty0 = (t / C::TPI_X) * C::TH; tx0 = (t % C::TPI_X) * C::TW; }
+        work_coords<C>(work, img0, ty0, tx0);
         __syncthreads();                       // previous tile's LDS reads are complete
-        stage_input_tile<C>(s_in, a.in, a.idx, a.in_base, a.lut, a.n, a.relu_in, img0, ty0, tx0);
+        tile_store<C>(regs, s_in, a.lut, a.relu_in);
         __syncthreads();
+        if (work + (int)gridDim.x < nwork) {   // next tile's loads fly during this tile's MFMAs
+            int i2, y2, x2;
+            work_coords<C>(work + gridDim.x, i2, y2, x2);
+            tile_load<C>(regs, a.in, a.idx, a.in_base, a.n, i2, y2, x2);
+        }
 
         f32x4 acc[C::MT][C::NB];
 #pragma unroll
@@ -216,23 +290,43 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
 
     const int nwork = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
-    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
-        int img0, ty0, tx0;
-        if (C::NIMG > 1) { img0 = work * C::NIMG; ty0 = 0; tx0 = 0; }
-        else { img0 = work / C::TPI; const int t = work % C::TPI; ty0 = (t / C::TPI_X) * C::TH; tx0 = (t % C::TPI_X) * C::TW; }
-        __syncthreads();
-        stage_input_tile<C>(s_in, a.in, a.idx, a.in_base, a.lut, a.n, a.relu_in, img0, ty0, tx0);
-        {
-            constexpr int C4 = C::COUT / 4;
-            for (int e = tid; e < C::NT * C4; e += 256) {
-                const int pl = e / C4, c4 = e % C4, y = pl / C::TW, x = pl % C::TW, n = img0 + y / C::TH;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    tile_clear<C>(s_in);
+    TileRegs<C> regs;
+    constexpr int OC4 = C::COUT / 4, NDO = (C::NT * OC4 + 255) / 256;
+    f32x4 dreg[NDO];
+    auto dout_load = [&](int i0, int y0, int x0) {
+#pragma unroll
+        for (int k = 0; k < NDO; ++k) {
+            const int e = tid + k * 256;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < C::NT * OC4) {
+                const int pl = e / OC4, c4 = e % OC4, y = pl / C::TW, x = pl % C::TW, n = i0 + y / C::TH;
                 if (n < a.n)
-                    v = *(const f32x4*)(a.dout + (((long long)n * C::HW + ty0 + (y % C::TH)) * C::HW + tx0 + x) * C::COUT + c4 * 4);
-                *(f32x4*)(s_do + pl * C::SO + c4 * 4) = v;
+                    v = *(const f32x4*)(a.dout + (((long long)n * C::HW + y0 + (y % C::TH)) * C::HW + x0 + x) * C::COUT + c4 * 4);
             }
+            dreg[k] = v;
+        }
+    };
+    int img0, ty0, tx0;
+    if ((int)blockIdx.x < nwork) {
+        work_coords<C>(blockIdx.x, img0, ty0, tx0);
+        tile_load<C>(regs, a.in, a.idx, a.in_base, a.n, img0, ty0, tx0);
+        dout_load(img0, ty0, tx0);
+    }
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        __syncthreads();
+        tile_store<C>(regs, s_in, a.lut, a.relu_in);
+#pragma unroll
+        for (int k = 0; k < NDO; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::NT * OC4) *(f32x4*)(s_do + (e / OC4) * C::SO + (e % OC4) * 4) = dreg[k];
         }
         __syncthreads();
+        if (work + (int)gridDim.x < nwork) {
+            work_coords<C>(work + gridDim.x, img0, ty0, tx0);
+            tile_load<C>(regs, a.in, a.idx, a.in_base, a.n, img0, ty0, tx0);
+            dout_load(img0, ty0, tx0);
+        }
 
 #pragma unroll 2
         for (int t = wave; t < C::NT / 4; t += 4) {
@@ -327,7 +421,9 @@ using W_16_32_32  = WgCfg<16, 16, 32, 32, 8, 32, 1, false>;
 using W_32_32_16  = WgCfg<32, 32, 32, 16, 8, 16, 1, false>;
 using W_32_32_8   = WgCfg<32, 32, 32,  8, 8,  8, 2, false>;
 
-static int g_max_blocks = 512;   // persistent grid: 2 workgroups per CU on a 256-CU part
+// persistent grids: as many workgroups per CU as the LDS footprint admits (max 4), on a 256-CU part
+template <class C>
+static int max_blocks() { int b = (int)((160 * 1024) / C::LDS_BYTES); b = b < 1 ? 1 : (b > 4 ? 4 : b); return 256 * b; }
 
 template <class C>
 static int work_items(int n) { return (C::NIMG > 1) ? (n + C::NIMG - 1) / C::NIMG : n * C::TPI; }
@@ -337,7 +433,7 @@ static void launch_fwd_t(const ConvArgs& a, hipStream_t st) {
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
     int grid = work_items<C>(a.n);
-    if (grid > g_max_blocks) grid = g_max_blocks;
+    if (grid > max_blocks<C>()) grid = max_blocks<C>();
     if (grid < 1) return;
     hipLaunchKernelGGL(conv3x3_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, st, a);
 }
@@ -347,7 +443,7 @@ static void launch_wg_t(const WgradArgs& a, hipStream_t st) {
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
     int grid = work_items<C>(a.n);
-    if (grid > g_max_blocks) grid = g_max_blocks;
+    if (grid > max_blocks<C>()) grid = max_blocks<C>();
     if (grid < 1) return;
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, st, a);
 }
@@ -378,17 +474,17 @@ void launch_conv_dgrad(ConvShape s, const ConvArgs& a, hipStream_t st) {
     }
 }
 
+template <class C>
+static int wg_grid_t(int n) { const int w = work_items<C>(n), m = max_blocks<C>(); return w > m ? m : w; }
 int wgrad_grid(ConvShape s, int n) {
-    int w = 0;
     switch (s) {
-        case CS_3_16_64:  w = work_items<W_3_16_64>(n); break;
-        case CS_16_16_32: w = work_items<W_16_16_32>(n); break;
-        case CS_16_32_32: w = work_items<W_16_32_32>(n); break;
-        case CS_32_32_16: w = work_items<W_32_32_16>(n); break;
-        case CS_32_32_8:  w = work_items<W_32_32_8>(n); break;
-        default: break;
+        case CS_3_16_64:  return wg_grid_t<W_3_16_64>(n);
+        case CS_16_16_32: return wg_grid_t<W_16_16_32>(n);
+        case CS_16_32_32: return wg_grid_t<W_16_32_32>(n);
+        case CS_32_32_16: return wg_grid_t<W_32_32_16>(n);
+        case CS_32_32_8:  return wg_grid_t<W_32_32_8>(n);
+        default: return 0;
     }
-    return w > g_max_blocks ? g_max_blocks : w;
 }
 
 void launch_conv_wgrad(ConvShape s, const WgradArgs& a, hipStream_t st) {

@@ -3,6 +3,7 @@
 // order: results are bitwise reproducible run to run (no float atomics anywhere).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -95,13 +96,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int k_chunk, floa
             }
 }
 
-__global__ void gemm_splitk_reduce(const float* ws, int split, int M, int N, float* C, long long ldc, int accumulate) {
+__global__ void gemm_splitk_reduce(const float* ws, int split, GemmArgs g) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long long)M * N) return;
-    float s = 0.f;
-    for (int z = 0; z < split; ++z) s += ws[(long long)z * M * N + e];
-    const long long o = (e / N) * ldc + (e % N);
-    C[o] = accumulate ? C[o] + s : s;
+    if (e >= (long long)g.M * g.N) return;
+    float v = 0.f;
+    for (int z = 0; z < split; ++z) v += ws[(long long)z * g.M * g.N + e];
+    const int n = (int)(e % g.N);
+    const long long o = (e / g.N) * g.ldc + n;
+    if (g.bias) v += g.bias[n];
+    if (g.relu_out) v = fmaxf(v, 0.f);
+    if (g.mask) v = g.mask[o] > 0.f ? v : 0.f;
+    if (g.accumulate) v += g.C[o];
+    g.C[o] = v;
 }
 
 static float* g_gemm_ws = nullptr;
@@ -112,11 +118,11 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return;
     const int tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
     int split = 1;
-    // weight-gradient shapes: few output tiles, long K (= batch).  Split K over workgroups and add
-    // the slabs in a fixed order (only plain accumulate epilogues use this path).
-    if (!g.bias && !g.mask && !g.relu_out && g.K >= 1024 && tm * tn < 256 && g_gemm_ws) {
+    // few output tiles and a long K (weight gradients: K = batch; rollout-sized forward GEMMs: M = n_envs):
+    // split K over workgroups, slabs summed in a fixed order by the reduce kernel (which carries the epilogue).
+    if (g.K >= 512 && tm * tn < 192 && g_gemm_ws) {
         split = 512 / (tm * tn);
-        if (split > g.K / 256) split = g.K / 256;
+        if (split > g.K / 128) split = g.K / 128;
         if (split < 1) split = 1;
         while (split > 1 && (size_t)split * g.M * g.N > g_gemm_ws_floats) --split;
     }
@@ -128,7 +134,7 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
         hipLaunchKernelGGL(gemm_kernel, dim3(tn, tm, split), dim3(256), 0, st, g, k_chunk, g_gemm_ws);
         const long long tot = (long long)g.M * g.N;
         hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
-                           (const float*)g_gemm_ws, split, g.M, g.N, g.C, g.ldc, g.accumulate);
+                           (const float*)g_gemm_ws, split, g);
     }
 }
 
@@ -136,77 +142,106 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
 // nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (common/model.py:158), NHWC.  The winner is the
 // FIRST maximum in (ky,kx) scan order (strict >), which is where torch's CPU kernel routes the
 // gradient; its window-relative position is kept as one byte per output for the backward pass.
-__global__ void maxpool_fwd_kernel(const float* in, float* out, uint8_t* arg, int n, int hw, int c) {
-    const int ho = hw / 2;
-    const long long tot = (long long)n * ho * ho * c;
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+template <int HW, int C>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          uint8_t* __restrict__ arg, int n) {
+    constexpr int HO = HW / 2, C4 = C / 4;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;          // one thread = 4 channels of one output pixel
+    const unsigned tot = (unsigned)n * HO * HO * C4;
     if (e >= tot) return;
-    const int ch = e % c;
-    long long r = e / c;
-    const int ox = r % ho; r /= ho;
-    const int oy = r % ho; const long long img = r / ho;
-    float best = -INFINITY;
-    int bi = 0;
+    const unsigned c4 = e % C4, ox = (e / C4) % HO, oy = (e / (C4 * HO)) % HO, img = e / (C4 * HO * HO);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned bi[4] = {0, 0, 0, 0};
     bool first = true;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int y = 2 * oy - 1 + ky, x = 2 * ox - 1 + kx;
-            if (y < 0 || y >= hw || x < 0 || x >= hw) continue;
-            const float v = in[((img * hw + y) * hw + x) * c + ch];
-            if (first || v > best || v != v) { best = v; bi = ky * 3 + kx; first = false; }
+            const int y = 2 * (int)oy - 1 + ky, x = 2 * (int)ox - 1 + kx;
+            if (y < 0 || y >= HW || x < 0 || x >= HW) continue;
+            const f32x4 v = *(const f32x4*)(in + (((size_t)img * HW + y) * HW + x) * C + c4 * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (first || v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = ky * 3 + kx; }
+            first = false;
         }
-    out[e] = best;
-    arg[e] = (uint8_t)bi;
+    *(f32x4*)(out + (size_t)e * 4) = best;
+    *(uint32_t*)(arg + (size_t)e * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
 }
 
-__global__ void maxpool_bwd_kernel(const float* dout, const uint8_t* arg, float* din, int n, int hw, int c) {
-    const int ho = hw / 2;
-    const long long tot = (long long)n * hw * hw * c;
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+template <int HW, int C>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ arg,
+                                                          float* __restrict__ din, int n) {
+    constexpr int HO = HW / 2, C4 = C / 4;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;          // 4 channels of one INPUT pixel
+    const unsigned tot = (unsigned)n * HW * HW * C4;
     if (e >= tot) return;
-    const int ch = e % c;
-    long long r = e / c;
-    const int x = r % hw; r /= hw;
-    const int y = r % hw; const long long img = r / hw;
-    float s = 0.f;
+    const unsigned c4 = e % C4, x = (e / C4) % HW, y = (e / (C4 * HW)) % HW, img = e / (C4 * HW * HW);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     // windows oy with 2*oy-1 <= y <= 2*oy+1
-    for (int oy = y / 2; oy <= (y + 1) / 2; ++oy) {
-        if (oy >= ho) continue;
-        for (int ox = x / 2; ox <= (x + 1) / 2; ++ox) {
-            if (ox >= ho) continue;
-            const long long o = ((img * ho + oy) * ho + ox) * c + ch;
-            const int pos = (y - (2 * oy - 1)) * 3 + (x - (2 * ox - 1));
-            if (arg[o] == pos) s += dout[o];
+    for (unsigned oy = y / 2; oy <= (y + 1) / 2; ++oy) {
+        if (oy >= HO) continue;
+        for (unsigned ox = x / 2; ox <= (x + 1) / 2; ++ox) {
+            if (ox >= HO) continue;
+            const size_t o = ((((size_t)img * HO + oy) * HO + ox) * C4 + c4) * 4;
+            const unsigned pos = (y - (2 * oy - 1)) * 3 + (x - (2 * ox - 1));
+            const uint32_t a = *(const uint32_t*)(arg + o);
+            const f32x4 d = *(const f32x4*)(dout + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (((a >> (8 * k)) & 0xffu) == pos) s[k] += d[k];
         }
     }
-    din[e] = s;
+    *(f32x4*)(din + (size_t)e * 4) = s;
 }
 
+template <int HW, int C>
+static void pool_fwd_t(const float* in, float* out, uint8_t* arg, int n, hipStream_t st) {
+    const unsigned tot = (unsigned)n * (HW / 2) * (HW / 2) * (C / 4);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<HW, C>), dim3((tot + 255) / 256), dim3(256), 0, st, in, out, arg, n);
+}
+template <int HW, int C>
+static void pool_bwd_t(const float* dout, const uint8_t* arg, float* din, int n, hipStream_t st) {
+    const unsigned tot = (unsigned)n * HW * HW * (C / 4);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<HW, C>), dim3((tot + 255) / 256), dim3(256), 0, st, dout, arg, din, n);
+}
 void launch_maxpool_fwd(const float* in, float* out, uint8_t* arg, int n, int hw, int c, hipStream_t st) {
-    const long long tot = (long long)n * (hw / 2) * (hw / 2) * c;
-    if (tot <= 0) return;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, in, out, arg, n, hw, c);
+    if (n <= 0) return;
+    if (hw == 64 && c == 16) pool_fwd_t<64, 16>(in, out, arg, n, st);
+    else if (hw == 32 && c == 32) pool_fwd_t<32, 32>(in, out, arg, n, st);
+    else if (hw == 16 && c == 32) pool_fwd_t<16, 32>(in, out, arg, n, st);
+    else abort();
 }
 void launch_maxpool_bwd(const float* dout, const uint8_t* arg, float* din, int n, int hw, int c, hipStream_t st) {
-    const long long tot = (long long)n * hw * hw * c;
-    if (tot <= 0) return;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dout, arg, din, n, hw, c);
+    if (n <= 0) return;
+    if (hw == 64 && c == 16) pool_bwd_t<64, 16>(dout, arg, din, n, st);
+    else if (hw == 32 && c == 32) pool_bwd_t<32, 32>(dout, arg, din, n, st);
+    else if (hw == 16 && c == 32) pool_bwd_t<16, 32>(dout, arg, din, n, st);
+    else abort();
 }
 
 // ------------------------------------------------------------------------------------------ slab / column reductions
-__global__ void reduce_slabs_kernel(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= slab_len) return;
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ partial, int nslab, int slab_len,
+                                                           float* dst_w, int n_w, float* dst_b, int n_b) {
+    __shared__ float sh[8][33];
+    const int ex = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + ex;
     float s = 0.f;
-    for (int b = 0; b < nslab; ++b) s += partial[(long long)b * slab_len + e];
-    if (e < n_w) dst_w[e] += s;
-    else if (e - n_w < n_b) dst_b[e - n_w] += s;
+    if (e < slab_len)
+        for (int b = g; b < nslab; b += 8) s += partial[(long long)b * slab_len + e];
+    sh[g][ex] = s;
+    __syncthreads();
+    if (g == 0 && e < slab_len) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][ex];
+        if (e < n_w) dst_w[e] += t;
+        else if (e - n_w < n_b) dst_b[e - n_w] += t;
+    }
 }
 void launch_reduce_slabs(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b, hipStream_t st) {
     if (nslab <= 0) return;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((slab_len + 255) / 256), dim3(256), 0, st, partial, nslab, slab_len, dst_w, n_w, dst_b, n_b);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((slab_len + 31) / 32), dim3(256), 0, st, partial, nslab, slab_len, dst_w, n_w, dst_b, n_b);
 }
 
 // db[n] += sum_m dY[m][n]   (bias gradients of the linear layers); 64 row groups x fixed order
