@@ -1,0 +1,173 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/mi355ppo.h declares,
+fails loudly without a GPU, the parameter layout / init / index-stream logic is bit-exact with the reference
+(golden vectors), and the data-parallel sharding helpers are consistent."""
+import hashlib
+import json
+import os
+import re
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, ROOT, load_npz, npz_json, npz_params
+
+
+def test_library_exports_every_declared_symbol():
+    from mi355 import engine as M
+    hdr = open(os.path.join(ROOT, "include", "mi355ppo.h")).read()
+    declared = sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", hdr)))
+    lib = M.load_library()
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(set(M.EXPORTS)) == [d for d in declared if d in M.EXPORTS]
+    assert set(declared) - set(M.EXPORTS) == set(), set(declared) - set(M.EXPORTS)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    from mi355.engine import Engine, EngineError
+    with pytest.raises(EngineError, match="no CPU fallback"):
+        Engine("impala", 4, 4, 15, 8)
+    from common.model import ImpalaModel
+    from common.policy import CategoricalPolicy
+    pol = CategoricalPolicy(ImpalaModel(3), False, 15)
+    with pytest.raises(NotImplementedError):
+        pol(torch.zeros(2, 3, 64, 64), None, None)          # no engine attached -> no compute path
+
+
+def test_init_is_bit_identical_to_reference():
+    """Same seed => same weights as the reference constructors (sha256 of the flat parameter vector)."""
+    from common.model import ImpalaModel, MLPModel
+    from common.policy import CategoricalPolicy
+    z = load_npz("g3_impala_forward.npz")
+    shas = npz_json(z, "sha")
+    for A in (15, 9):
+        torch.manual_seed(6033)
+        p = CategoricalPolicy(ImpalaModel(in_channels=3), False, A)
+        flat = np.concatenate([x.detach().numpy().ravel() for x in p.parameters()]).astype(np.float32)
+        assert hashlib.sha256(flat.tobytes()).hexdigest() == shas[f"A{A}"]
+        assert sum(x.numel() for x in p.parameters()) == (626256 if A == 15 else 624714)
+    assert list(p.state_dict().keys()) == [k[2:] for k in z.files if k.startswith("p/")]
+    z7 = load_npz("g7_mlp_forward.npz")
+    torch.manual_seed(6033)
+    p = CategoricalPolicy(MLPModel(9, 4, 256, 64), False, 2)
+    flat = np.concatenate([x.detach().numpy().ravel() for x in p.parameters()]).astype(np.float32)
+    assert hashlib.sha256(flat.tobytes()).hexdigest() == bytes(z7["sha"]).decode()
+    assert list(p.state_dict().keys()) == [k[2:] for k in z7.files if k.startswith("p/")]
+
+
+def test_layout_roundtrip_and_order():
+    from mi355 import layout
+    z = load_npz("g3_impala_forward.npz")
+    shapes = layout.impala_param_shapes(15)
+    assert list(shapes.keys()) == [k[2:] for k in z.files if k.startswith("p/")]
+    flat = layout.flatten(shapes, npz_params(z))
+    assert flat.size == 626256
+    back = layout.unflatten(shapes, flat)
+    assert all(np.array_equal(back[k], npz_params(z)[k]) for k in shapes)
+    with pytest.raises(ValueError):
+        layout.unflatten(shapes, flat[:-1])
+    assert sum(int(np.prod(s)) for s in layout.mlp_param_shapes(2, 9, 4, 256, 64).values()) == 150787
+
+
+def test_index_streams_bit_exact_with_reference():
+    """Storage.minibatch_index_stream consumes the torch CPU generator exactly like the reference's
+    BatchSampler(SubsetRandomSampler) / randperm(E) (golden G2)."""
+    from common.storage import Storage
+    rec = json.load(open(os.path.join(GOLD, "g2_perm.json")))
+    for key, r in rec.items():
+        if key.startswith("rec_"):
+            _, s, e = key.split("_")
+            E = int(e[1:])
+            st = Storage((9,), 4, 4, E, None)
+            torch.manual_seed(int(s[1:]))
+            groups = list(st.minibatch_index_stream(4 * E, recurrent=True))
+            assert len(groups) == 1
+            envs = groups[0][:E]                                   # first time step: t = 0 -> flat index == env
+            assert envs[:16].tolist() == r["first16"]
+            assert zlib.crc32(envs.astype(np.int64).tobytes()) == r["crc_all"]
+            assert np.array_equal(groups[0].reshape(4, E), np.arange(4)[:, None] * E + envs[None, :])   # time-major
+            continue
+        s, T, E, B = key.split("_")
+        seed, T, E, B = int(s[1:]), int(T[1:]), int(E[1:]), int(B[1:])
+        st = Storage((9,), 4, T, E, None)
+        torch.manual_seed(seed)
+        chunks = list(st.minibatch_index_stream(B)) + list(st.minibatch_index_stream(B))
+        assert len(chunks) == r["n_chunks"]
+        allidx = np.concatenate(chunks)
+        assert allidx.dtype == np.int64
+        assert allidx[:16].tolist() == r["first16"] and allidx[-16:].tolist() == r["last16"]
+        assert zlib.crc32(allidx.tobytes()) == r["crc_all"]
+        assert [zlib.crc32(c.tobytes()) for c in chunks] == r["crc_chunks"]
+
+
+def test_recurrent_groups_match_reference_generator():
+    from common.storage import Storage
+    z = load_npz("g8_recurrent.npz")
+    meta = npz_json(z, "meta")
+    T, E, B = meta["T"], meta["E"], meta["B"]
+    st = Storage((5,), 6, T, E, None)
+    torch.manual_seed(meta["seed"])
+    groups = list(st.minibatch_index_stream(B, recurrent=True))
+    assert len(groups) == len(meta["shapes"])
+    val = z["val"][:-1].reshape(-1)
+    act = z["act"].reshape(-1)
+    for idx, sh, first in zip(groups, meta["shapes"], meta["first"]):
+        assert len(idx) == sh[0][0]
+        np.testing.assert_array_equal(act[idx], np.asarray(first["act"], dtype=np.float32))
+        np.testing.assert_allclose(val[idx], first["val"], atol=1e-7)
+
+
+def test_shard_indices_partition_and_order():
+    from mi355.dist import env_range, merge_adv_stats, shard_indices
+    T, E, W = 16, 24, 4
+    rng = np.random.default_rng(0)
+    chunk = rng.permutation(T * E)[:100]
+    seen = []
+    for r in range(W):
+        loc = shard_indices(chunk, E, r, W)
+        e0, e1 = env_range(E, r, W)
+        El = e1 - e0
+        t, e = loc // El, loc % El + e0
+        glob = t * E + e
+        # order preserved, every element belongs to the shard
+        assert np.array_equal(glob, chunk[(chunk % E >= e0) & (chunk % E < e1)])
+        seen.append(glob)
+    assert sorted(np.concatenate(seen).tolist()) == sorted(chunk.tolist())
+    assert np.array_equal(shard_indices(chunk, E, 0, 1), chunk)
+    with pytest.raises(ValueError):
+        env_range(10, 0, 4)
+    # Chan merge == statistics of the concatenation
+    parts = [rng.standard_normal(n) * (k + 1) + k for k, n in enumerate((5, 1000, 37))]
+    stats = [(len(p), p.mean(), ((p - p.mean()) ** 2).sum()) for p in parts]
+    n, mean, m2 = merge_adv_stats(stats)
+    allp = np.concatenate(parts)
+    assert n == len(allp) and abs(mean - allp.mean()) < 1e-12 and abs(m2 / (n - 1) - allp.var(ddof=1)) < 1e-10
+
+
+def test_as_device_obs_is_lossless():
+    from common.model import as_device_obs
+    u8 = np.random.default_rng(1).integers(0, 256, (3, 64, 64, 3), dtype=np.uint8)
+    ref_obs = u8.transpose(0, 3, 1, 2) / 255.0                       # what the reference's wrappers hand the agent
+    assert np.array_equal(as_device_obs(ref_obs, "impala"), u8)
+    assert np.array_equal(as_device_obs(torch.from_numpy(ref_obs.astype(np.float32)), "impala"), u8)
+    assert np.array_equal(as_device_obs(u8, "impala"), u8)
+    # and the table the kernels use reproduces the reference's float32 observation exactly
+    lut = (np.arange(256) / 255.0).astype(np.float32)
+    assert np.array_equal(lut[u8].transpose(0, 3, 1, 2), ref_obs.astype(np.float32))
+
+
+def test_lr_schedule_and_config():
+    import yaml
+    from common.misc_util import adjust_lr
+
+    class Opt:
+        param_groups = [{"lr": 1.0}]
+    o, lr = adjust_lr(Opt(), 5e-4, 65536, 200_000_000)
+    assert lr == 5e-4 * (1 - 65536 / 200_000_000) and o.param_groups[0]["lr"] == lr
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "train-procgen-pytorch_amd", "hyperparams", "procgen", "config.yml")))
+    hp = cfg["hard-500"]
+    assert (hp["n_envs"], hp["n_steps"], hp["mini_batch_size"], hp["epoch"]) == (256, 256, 8192, 3)
+    assert cfg["easy"]["mini_batch_size"] == 2048 and cfg["cartpole"]["architecture"] == "mlpmodel"

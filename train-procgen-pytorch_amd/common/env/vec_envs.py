@@ -1,0 +1,95 @@
+"""Host-side vectorised environments that speak the baselines VecEnv protocol the agent drives
+(reset() -> obs ; step(act) -> (obs, rew, done, info) ; close()), reference:
+common/env/procgen_wrappers.py:45-124.  Rollout collection stays on the host (north_star).
+
+* CartPoleVec   -- a from-scratch numpy cart-pole (classic Barto/Sutton dynamics, Euler, tau 0.02) with
+                   auto-reset, the plumbing config C1 (MLP policy).
+* SyntheticFrames -- random uint8 64x64x3 frames, N(0,1) rewards, Bernoulli(0.01) dones: the synthetic
+                   learner-side workload of SURVEY 8(d) / bench.py.
+* create_procgen_env -- the real engine if the `procgen` package is importable (it is not in the build image).
+"""
+import numpy as np
+
+
+class _Space:
+    def __init__(self, shape=None, n=None):
+        self.shape, self.n = shape, n
+
+
+class CartPoleVec:
+    gravity, masscart, masspole, length, force_mag, tau = 9.8, 1.0, 0.1, 0.5, 10.0, 0.02
+    x_threshold, theta_threshold = 2.4, 12 * 2 * np.pi / 360
+
+    def __init__(self, n_envs, max_steps=500, seed=0):
+        self.n_envs, self.max_steps = n_envs, max_steps
+        self.rng = np.random.default_rng(seed)
+        self.observation_space = _Space(shape=(4,))
+        self.action_space = _Space(n=2)
+        self.state = np.zeros((n_envs, 4))
+        self.steps = np.zeros(n_envs, dtype=np.int64)
+
+    def _fresh(self, k):
+        return self.rng.uniform(-0.05, 0.05, size=(k, 4))
+
+    def reset(self):
+        self.state = self._fresh(self.n_envs)
+        self.steps[:] = 0
+        return self.state.astype(np.float32)
+
+    def step(self, act):
+        x, xd, th, thd = self.state.T
+        force = np.where(np.asarray(act) == 1, self.force_mag, -self.force_mag)
+        total_m, pml = self.masscart + self.masspole, self.masspole * self.length
+        ct, st = np.cos(th), np.sin(th)
+        temp = (force + pml * thd ** 2 * st) / total_m
+        thacc = (self.gravity * st - ct * temp) / (self.length * (4.0 / 3.0 - self.masspole * ct ** 2 / total_m))
+        xacc = temp - pml * thacc * ct / total_m
+        self.state = np.stack([x + self.tau * xd, xd + self.tau * xacc, th + self.tau * thd, thd + self.tau * thacc], axis=1)
+        self.steps += 1
+        fell = (np.abs(self.state[:, 0]) > self.x_threshold) | (np.abs(self.state[:, 2]) > self.theta_threshold)
+        done = fell | (self.steps >= self.max_steps)
+        rew = np.ones(self.n_envs, dtype=np.float32)
+        info = [{} for _ in range(self.n_envs)]
+        if done.any():
+            k = int(done.sum())
+            self.state[done] = self._fresh(k)
+            self.steps[done] = 0
+        return self.state.astype(np.float32), rew, done, info
+
+    def close(self):
+        pass
+
+
+class SyntheticFrames:
+    def __init__(self, n_envs, n_actions=15, seed=0, pool=8):
+        self.n_envs = n_envs
+        self.rng = np.random.default_rng(seed)
+        self.observation_space = _Space(shape=(3, 64, 64))
+        self.action_space = _Space(n=n_actions)
+        self._pool = [self.rng.integers(0, 256, size=(n_envs, 64, 64, 3), dtype=np.uint8) for _ in range(pool)]
+        self._k = 0
+
+    def _obs(self):
+        self._k = (self._k + 1) % len(self._pool)
+        return self._pool[self._k]                       # uint8 NHWC: what Procgen's 'rgb' delivers
+
+    def reset(self):
+        return self._obs()
+
+    def step(self, act):
+        rew = self.rng.standard_normal(self.n_envs).astype(np.float32)
+        done = self.rng.random(self.n_envs) < 0.01
+        info = [{"env_reward": float(r), "prev_level_seed": e % 500} for e, r in enumerate(rew)]
+        return self._obs(), rew, done, info
+
+    def close(self):
+        pass
+
+
+def create_procgen_env(*args, **kwargs):
+    try:
+        import procgen  # noqa: F401
+    except ImportError as e:
+        raise NotImplementedError("the Procgen C++ engine (procgen==0.10.7) is not installed in this image; "
+                                  "use --env_name synthetic or cartpole") from e
+    raise NotImplementedError("Procgen wrapper chain -> uint8 NHWC producer is the next row of SURVEY 8(f)")
