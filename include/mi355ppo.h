@@ -88,6 +88,18 @@ int mi_predict_staged(mi_ctx* ctx, const void* obs, size_t bytes, uint64_t seed,
                       int64_t* act_out, float* logp_out, float* value_out);
 int mi_commit_staged(mi_ctx* ctx, int32_t t);
 
+/* ---- recurrent policies (CategoricalPolicy(recurrent=True), common/policy.py:48-50,66-67; GRU.forward prediction
+ *      branch, common/model.py:219-225): h' = GRU(feat, h * (1 - done)), heads on h'.  As in the reference's
+ *      algo: ppo the GRU runs in predict only and is never trained: its weights are set once,
+ *      in nn.GRU's layout (weight_ih_l0 (3H,H), weight_hh_l0 (3H,H), bias_ih_l0 (3H), bias_hh_l0 (3H); gates r,z,n).
+ *      mi_rec_state sets the hidden state (NULL keeps the device copy) and the done flags (NULL = zeros) that the
+ *      NEXT mi_policy_step / mi_predict_staged consumes; mi_get_hidden reads the state after it. */
+int mi_set_gru(mi_ctx* ctx, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh);
+int mi_rec_state(mi_ctx* ctx, const float* hidden /* E x H or NULL */, const float* done /* E or NULL */);
+int mi_get_hidden(mi_ctx* ctx, float* hidden /* E x H */);
+/* policy(obs, hx, masks) for a recurrent policy on E observations: consumes / advances the state like a policy step */
+int mi_forward_rec(mi_ctx* ctx, const void* obs, float* logp_all, float* value, float* hidden_out);
+
 /* ---- stateless forward on caller data (policy(obs, hx, masks) / hidden_to_output, common/policy.py:61-87).
  *      obs: n frames uint8 NHWC or n x obs_dim fp32.  logp_all: n x A normalised log-probs
  *      (Categorical.logits); value: n; feat: n x out_dim.  Outputs may be NULL. */

@@ -86,6 +86,19 @@ def heads(p, feat):
     return lp, value
 
 
+def gru_cell(p, x, h, mask):
+    """GRU.forward prediction branch (common/model.py:219-225): one nn.GRU step on h * mask.
+    p holds gru.gru.{weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0}; gate order r, z, n."""
+    hm = h * mask.reshape(-1, 1)
+    gi = F.linear(x, p["gru.gru.weight_ih_l0"], p["gru.gru.bias_ih_l0"])
+    gh = F.linear(hm, p["gru.gru.weight_hh_l0"], p["gru.gru.bias_hh_l0"])
+    H = h.shape[1]
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1 - z) * n + z * hm
+
+
 def policy_forward(p, arch, obs):
     """-> (logp_all, value, fs or None)."""
     if arch == "impala":

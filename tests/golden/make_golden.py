@@ -383,6 +383,34 @@ def g8_recurrent():
                                            np.uint8))
 
 
+# --------------------------------------------------------------------------- G9 (recurrent predict path)
+def g9_recurrent_predict():
+    """CategoricalPolicy(recurrent=True).forward for three consecutive rollout steps (policy.py:61-72 ->
+    GRU.forward prediction branch, model.py:219-225): hidden carried, masked by 1 - done."""
+    torch.manual_seed(6033)
+    model = ImpalaModel(in_channels=3)
+    policy = CategoricalPolicy(model, True, 15)
+    out = {}
+    for k, v in sd_numpy(policy).items():
+        if k.startswith("gru."):
+            out["p/" + k] = v
+    out["sha_all"] = np.frombuffer(flat_sha(policy).encode(), np.uint8)
+    out["keys"] = np.frombuffer(json.dumps(list(policy.state_dict().keys())).encode(), np.uint8)
+    rng = np.random.default_rng(23)
+    E = 8
+    frames = rng.integers(0, 256, size=(3, E, 64, 64, 3), dtype=np.uint8)
+    done = np.stack([np.zeros(E), (rng.random(E) < 0.4).astype(np.float64), (rng.random(E) < 0.4).astype(np.float64)])
+    hx = torch.zeros(E, 256)
+    out["frames"], out["done"] = frames, done.astype(np.float32)
+    with torch.no_grad():
+        for t in range(3):
+            x = torch.FloatTensor(frames_to_ref_obs(frames[t]))
+            mask = torch.FloatTensor(1 - done[t])
+            dist, value, hx = policy(x, hx, mask)
+            out[f"logits{t}"], out[f"value{t}"], out[f"hx{t}"] = dist.logits.numpy(), value.numpy(), hx.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g9_recurrent_predict.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     g1_gae(); print("G1 done")
@@ -393,3 +421,4 @@ if __name__ == "__main__":
         g4_loss_grad(arch); print("G4", arch, "done")
         g56_optimize(arch); print("G5/6", arch, "done")
     g8_recurrent(); print("G8 done")
+    g9_recurrent_predict(); print("G9 done")

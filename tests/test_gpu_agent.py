@@ -106,6 +106,46 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     assert np.array_equal(m1, m2) and np.array_equal(v1, v2) and agent2.optimizer.step_count == 4
 
 
+def test_recurrent_policy_golden_and_agent_flow():
+    """C5 path: GRU cell in the rollout only (golden G9 from the reference), recurrent env-group minibatches,
+    and -- like the reference -- an update that never touches the GRU."""
+    from agents.ppo import PPO
+    from common.env.vec_envs import SyntheticFrames
+    from common.model import ImpalaModel
+    from common.policy import CategoricalPolicy
+    from common.storage import Storage
+    from conftest import load_npz
+    z = load_npz("g9_recurrent_predict.npz")
+    T, E = 4, 8
+    torch.manual_seed(6033)
+    policy = CategoricalPolicy(ImpalaModel(3), True, 15)
+    storage = Storage((3, 64, 64), 256, T, E, torch.device("cuda", 0))
+    agent = PPO(None, policy, _Log(), storage, torch.device("cuda", 0), 1, n_steps=T, n_envs=E, epoch=1, n_minibatch=2,
+                mini_batch_size=16, gamma=0.999, lmbda=0.95, learning_rate=5e-4)
+    hx = torch.zeros(E, 256)
+    for t in range(3):
+        dist, value, hx = policy(z["frames"][t], hx, torch.from_numpy(1.0 - z["done"][t]))
+        np.testing.assert_allclose(hx.numpy(), z[f"hx{t}"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(dist.logits.numpy(), z[f"logits{t}"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(value.numpy(), z[f"value{t}"], rtol=0, atol=2e-5)
+    # rollout + update through the agent: hidden state carried on the device, stored per step on the host mirror
+    env = SyntheticFrames(E, 15, seed=3)
+    gru_before = [t.detach().clone() for t in policy.gru.parameters()]
+    obs, hid, done = agent._collect(env, agent.engine, storage, env.reset(), np.zeros((E, 256), np.float32), np.zeros(E, np.float32))
+    assert np.abs(hid).max() > 0 and np.abs(storage.hidden_states_batch.numpy()[1]).max() > 0
+    assert not storage.hidden_states_batch.numpy()[0].any()                # step 0 stored the zero input state
+    storage.compute_estimates(0.999, 0.95, True, True)
+    torch.manual_seed(3)
+    groups = list(storage.minibatch_index_stream(16, True))
+    assert len(groups) == 2 and all(len(g) == 16 for g in groups)
+    torch.manual_seed(3)
+    summary = agent.optimize()
+    assert np.isfinite(summary["Loss/total"])
+    assert all(torch.equal(a, b) for a, b in zip(gru_before, policy.gru.parameters()))
+    sd = agent.optimizer.state_dict()
+    assert len(sd["param_groups"][0]["params"]) == 40 and len(sd["state"]) == 36      # frozen GRU: no Adam state
+
+
 def test_cartpole_learns():
     """Config C1 plumbing end to end: MLP policy + numpy cart-pole; mean episode length must grow."""
     from agents.ppo import PPO

@@ -58,6 +58,18 @@ def test_init_is_bit_identical_to_reference():
     assert list(p.state_dict().keys()) == [k[2:] for k in z7.files if k.startswith("p/")]
 
 
+def test_recurrent_policy_init_and_keys_match_reference():
+    from common.model import ImpalaModel
+    from common.policy import CategoricalPolicy
+    z = load_npz("g9_recurrent_predict.npz")
+    torch.manual_seed(6033)
+    p = CategoricalPolicy(ImpalaModel(3), True, 15)
+    flat = np.concatenate([x.detach().numpy().ravel() for x in p.parameters()]).astype(np.float32)
+    assert hashlib.sha256(flat.tobytes()).hexdigest() == bytes(z["sha_all"]).decode()
+    assert list(p.state_dict().keys()) == npz_json(z, "keys")
+    assert len(p.param_shapes()) == 36                       # the frozen GRU is not part of the trained flat vector
+
+
 def test_layout_roundtrip_and_order():
     from mi355 import layout
     z = load_npz("g3_impala_forward.npz")

@@ -190,3 +190,19 @@ def test_g8_recurrent_generator_shapes():
         np.testing.assert_allclose(act[:, gidx].reshape(-1), first["act"], atol=0)
         np.testing.assert_allclose(val[:-1][:, gidx].reshape(-1), first["val"], atol=1e-7)
     assert meta["nonrec_shapes"][1] == [T * E, 6]      # un-indexed hidden batch quirk (storage.py:114-116)
+
+
+def test_g9_recurrent_predict():
+    """GRU prediction branch (rollout only): three steps with carried, done-masked hidden state."""
+    z = load_npz("g9_recurrent_predict.npz")
+    p = _tparams(npz_params(load_npz("g3_impala_forward.npz")))        # same seed => same embedder + heads
+    p.update(_tparams(npz_params(z)))
+    h = torch.zeros(8, 256)
+    with torch.no_grad():
+        for t in range(3):
+            feat, _, _ = O.impala_embed(p, O.frames_to_obs(z["frames"][t]))
+            h = O.gru_cell(p, feat, h, torch.from_numpy(1.0 - z["done"][t]))
+            lp, v = O.heads(p, h)
+            np.testing.assert_allclose(h.numpy(), z[f"hx{t}"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(lp.numpy(), z[f"logits{t}"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(v.numpy(), z[f"value{t}"], rtol=0, atol=2e-6)

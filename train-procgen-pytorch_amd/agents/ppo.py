@@ -69,6 +69,9 @@ class PPO(BaseAgent):
                                        obs_dim=getattr(emb, "input_size", 0), mlp_depth=getattr(emb, "depth", 0),
                                        mlp_width=getattr(emb, "mid_weight", 0), out_dim=emb.output_dim, device=dev_index)
             storage_valid.attach_engine(self.engine_valid)
+            if policy.is_recurrent():
+                g = policy.gru.gru
+                self.engine_valid.set_gru(*(t.detach().numpy() for t in (g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)))
         self.optimizer = DeviceAdam(policy, self.engine, learning_rate, eps=1e-5)
         self._grads_t = self._stats_t = None
         if self.coll.active:
@@ -90,26 +93,32 @@ class PPO(BaseAgent):
         return np.uint8 if arch == "impala" else np.float32
 
     # ------------------------------------------------------------------ predict
-    def _predict_into(self, engine, storage, t, obs):
-        """Upload obs into ring slot t (pinned double buffer), forward + sample on the device."""
+    def _predict_into(self, engine, storage, t, obs, hidden_state=None, done=None):
+        """Upload obs into ring slot t (pinned double buffer), forward (+ GRU cell) + sample on the device."""
         buf = self._stage[self._stage_i]
         self._stage_i ^= 1
         buf[...] = as_device_obs(obs, self.policy.arch)
         engine.put_obs(t, buf)
+        rec = self.policy.is_recurrent()
+        if rec:
+            engine.rec_state(hidden_state, done)
         act, logp, value = engine.policy_step(t, seed=self.seed * 1000003 + self._iter)
         storage.note_predicted(t, obs, act, logp, value)
-        return act, logp, value
+        return act, logp, value, (engine.get_hidden() if rec else hidden_state)
 
     def predict(self, obs, hidden_state, done):
         """agents/ppo.py:72-81.  The observation is staged on the device; the ``Storage.store`` /
         ``store_last`` call that follows with the same array commits it into its slot on the device, so the
         frames cross PCIe once."""
         self._predict_calls = getattr(self, "_predict_calls", 0) + 1
+        rec = self.policy.is_recurrent()
+        if rec:
+            self.engine.rec_state(hidden_state, done)
         act, logp, value = self.engine.predict_staged(as_device_obs(obs, self.policy.arch),
                                                       seed=self.seed * 1000003 + self._iter,
                                                       counter=self._predict_calls * self.n_envs)
         self.storage.note_predicted(-1, obs, act, logp, value)
-        return act, logp, value, np.asarray(hidden_state)
+        return act, logp, value, (self.engine.get_hidden() if rec else np.asarray(hidden_state))
 
     def predict_w_value_saliency(self, obs, hidden_state, done):
         raise NotImplementedError("value saliency (input gradient) is a 'next' row of SURVEY 8(f), not built yet")
@@ -160,11 +169,11 @@ class PPO(BaseAgent):
     def _collect(self, env, engine, storage, obs, hidden_state, done):
         for _ in range(self.n_steps):
             t = storage.step
-            act, logp, value = self._predict_into(engine, storage, t, obs)
+            act, logp, value, next_hidden = self._predict_into(engine, storage, t, obs, hidden_state, done)
             next_obs, rew, done, info = env.step(act)
             storage.store(obs, hidden_state, act, rew, done, info, logp, value)
-            obs = next_obs
-        _, _, last_val = self._predict_into(engine, storage, self.n_steps, obs)
+            obs, hidden_state = next_obs, next_hidden
+        _, _, last_val, hidden_state = self._predict_into(engine, storage, self.n_steps, obs, hidden_state, done)
         storage.store_last(obs, hidden_state, last_val)
         return obs, hidden_state, done
 

@@ -111,12 +111,13 @@ class MLPModel(_EngineBacked):
 
 
 class GRU(nn.Module):
-    """Container for the recurrent wrapper (model.py:212-216).  In ``algo: ppo`` the reference uses the GRU in
-    predict only and never trains it; its device kernel is not built yet."""
+    """Weights of the recurrent wrapper (model.py:212-216; orthogonal_init is a no-op on nn.GRU, so torch's
+    default uniform init stays).  In ``algo: ppo`` the reference runs the GRU in predict only and never trains it
+    (SURVEY 8(a) A9): the cell runs inside the engine's policy step (csrc/misc.hip gru_gates_kernel)."""
 
     def __init__(self, input_size, hidden_size):
         super().__init__()
         self.gru = orthogonal_init(nn.GRU(input_size, hidden_size), gain=1.0)
 
     def forward(self, x, hxs, masks):
-        raise NotImplementedError("recurrent rollout (GRU cell) is not implemented on the MI355X path yet")
+        raise NotImplementedError("the GRU cell runs inside the engine's policy step; call policy(obs, hx, masks)")

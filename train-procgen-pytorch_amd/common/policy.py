@@ -55,6 +55,9 @@ class CategoricalPolicy(nn.Module):
     def attach_engine(self, engine):
         object.__setattr__(self, "engine", engine)
         self.sync_to_device()
+        if self.recurrent:
+            g = self.gru.gru
+            engine.set_gru(*(t.detach().numpy() for t in (g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)))
 
     def sync_to_device(self):
         self.engine.set_params(layout.flatten(self.param_shapes(), self._host_tensors()))
@@ -89,10 +92,13 @@ class CategoricalPolicy(nn.Module):
         return self.recurrent
 
     def forward(self, x, hx, masks):
-        if self.recurrent:
-            raise NotImplementedError("recurrent rollout (GRU cell) is not implemented on the MI355X path yet")
         if self.engine is None:
             self.embedder._policy()        # raises with the explanation
+        if self.recurrent:
+            to_np = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+            self.engine.rec_state(to_np(hx), 1.0 - to_np(masks))
+            lp, value, hid = self.engine.forward_rec(as_device_obs(x, self.arch))
+            return Categorical(logits=torch.from_numpy(lp)), torch.from_numpy(value), torch.from_numpy(hid)
         lp, value = self.engine.forward(as_device_obs(x, self.arch))
         return Categorical(logits=torch.from_numpy(lp)), torch.from_numpy(value), hx
 

@@ -93,6 +93,8 @@ struct mi_ctx {
     double* sumsq; float* gnorm;
     float* d_u; float* d_lp;
     int32_t* s_act; float *s_logp, *s_val; bool staged_valid;
+    // recurrent rollout (GRU cell, never trained)
+    bool gru_on; float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *h_state, *h_masked, *gru_gi, *gru_gh, *d_done;
     // pinned host staging
     // index staging ring: a slot is rewritten only after the H2D copy that read it has completed
     static constexpr int IDX_RING = 8;
@@ -299,6 +301,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
     c->multirank = 0; c->pending_n = -1;
+    c->gru_on = false; c->gru_wih = c->gru_whh = c->gru_bih = c->gru_bhh = c->h_state = c->h_masked = c->gru_gi = c->gru_gh = c->d_done = nullptr;
     HIPC(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -320,6 +323,7 @@ int mi_destroy(mi_ctx* c) {
     if (c->frames) hipFree(c->frames);
     if (c->stage_frames) hipFree(c->stage_frames);
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
+    { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
     hipHostFree(c->h_f); hipHostFree(c->h_i);
@@ -544,7 +548,19 @@ static void linear_wgrad(mi_ctx* c, const float* dY, const float* X, int relu_x,
     launch_colsum_acc(dY, n, out, out, gb, c->stream);
 }
 
-static void net_forward(mi_ctx* c, const InputSrc& src, int n) {
+static void net_heads(mi_ctx* c, int n) {
+    linear_fwd(c, c->feat, 0, c->params + c->wh_off, c->params + c->bh_off, c->hout, n, c->H, c->A + 1, 0);
+}
+// h' = GRU(feat, h_state * (1 - done)); feat <- h' ; h_state <- h'   (n == E rows)
+static void net_gru(mi_ctx* c, int n) {
+    const int H = c->H;
+    launch_mask_rows(c->h_state, c->d_done, c->h_masked, n, H, c->stream);
+    linear_fwd(c, c->feat, 0, c->gru_wih, c->gru_bih, c->gru_gi, n, H, 3 * H, 0);
+    linear_fwd(c, c->h_masked, 0, c->gru_whh, c->gru_bhh, c->gru_gh, n, H, 3 * H, 0);
+    launch_gru_gates(c->gru_gi, c->gru_gh, c->h_masked, c->h_state, c->feat, n, H, c->stream);
+}
+
+static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = false) {
     if (c->cfg.arch == MI_ARCH_IMPALA) {
         const float* prev = nullptr;
         for (int b = 0; b < 3; ++b) {
@@ -568,7 +584,8 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n) {
             linear_fwd(c, c->mlp_act[l], 0, c->params + c->mlp[l].w_off, c->params + c->mlp[l].b_off, y, n, c->mlp[l].in, c->mlp[l].out, l + 1 < L);
         }
     }
-    linear_fwd(c, c->feat, 0, c->params + c->wh_off, c->params + c->bh_off, c->hout, n, c->H, c->A + 1, 0);
+    if (recurrent && c->gru_on) net_gru(c, n);
+    net_heads(c, n);
 }
 
 // backward from dY (n x (A+1)); gradients accumulate into c->grads
@@ -624,7 +641,7 @@ int mi_policy_step(mi_ctx* c, int32_t t, uint64_t seed, const float* u, int64_t*
     const float* du = nullptr;
     if (u) { HIPC(hipMemcpyAsync(c->d_u, u, (size_t)E * 4, hipMemcpyHostToDevice, c->stream)); du = c->d_u; }
     c->prof.phase = 0;
-    net_forward(c, src, E);
+    net_forward(c, src, E, true);
     const bool last = (t == c->T);
     launch_sample(c->hout, E, c->A, du, seed, (unsigned long long)t * E, last ? nullptr : c->act + (size_t)t * E,
                   last ? nullptr : c->logp + (size_t)t * E, c->value + (size_t)t * E, c->stream);
@@ -650,7 +667,7 @@ int mi_predict_staged(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, u
     const float* du = nullptr;
     if (u) { HIPC(hipMemcpyAsync(c->d_u, u, (size_t)E * 4, hipMemcpyHostToDevice, c->stream)); du = c->d_u; }
     InputSrc src{stage, nullptr, 0};
-    net_forward(c, src, E);
+    net_forward(c, src, E, true);
     launch_sample(c->hout, E, c->A, du, seed, counter, c->s_act, c->s_logp, c->s_val, c->stream);
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(c->h_i, c->s_act, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
@@ -678,13 +695,51 @@ int mi_commit_staged(mi_ctx* c, int32_t t) {
     return 0;
 }
 
+int mi_set_gru(mi_ctx* c, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh) {
+    ARG(c && w_ih && w_hh && b_ih && b_hh, "null");
+    const size_t H = c->H, E = c->E;
+    if (!c->gru_wih) {
+        HIPC(dalloc(&c->gru_wih, 3 * H * H)); HIPC(dalloc(&c->gru_whh, 3 * H * H)); HIPC(dalloc(&c->gru_bih, 3 * H)); HIPC(dalloc(&c->gru_bhh, 3 * H));
+        HIPC(dalloc(&c->h_state, E * H)); HIPC(dalloc(&c->h_masked, E * H)); HIPC(dalloc(&c->gru_gi, E * 3 * H)); HIPC(dalloc(&c->gru_gh, E * 3 * H));
+        HIPC(dalloc(&c->d_done, E));
+    }
+    HIPC(hipMemcpy(c->gru_wih, w_ih, 3 * H * H * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(c->gru_whh, w_hh, 3 * H * H * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(c->gru_bih, b_ih, 3 * H * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(c->gru_bhh, b_hh, 3 * H * 4, hipMemcpyHostToDevice));
+    c->gru_on = true;
+    return 0;
+}
+int mi_rec_state(mi_ctx* c, const float* hidden, const float* done) {
+    ARG(c, "null"); ARG(c->gru_on, "no GRU set: call mi_set_gru first");
+    const size_t H = c->H, E = c->E;
+    if (hidden) HIPC(hipMemcpyAsync(c->h_state, hidden, E * H * 4, hipMemcpyHostToDevice, c->stream));
+    if (done) HIPC(hipMemcpyAsync(c->d_done, done, E * 4, hipMemcpyHostToDevice, c->stream));
+    else HIPC(hipMemsetAsync(c->d_done, 0, E * 4, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int mi_get_hidden(mi_ctx* c, float* hidden) {
+    ARG(c && hidden, "null"); ARG(c->gru_on, "no GRU set");
+    HIPC(hipMemcpyAsync(hidden, c->h_state, (size_t)c->E * c->H * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int forward_common(mi_ctx* c, const void* obs, int32_t n, bool recurrent, float* logp_all, float* value, float* feat);
+int mi_forward_rec(mi_ctx* c, const void* obs, float* logp_all, float* value, float* hidden_out) {
+    ARG(c && obs, "null"); ARG(c->gru_on, "no GRU set");
+    int r = forward_common(c, obs, c->E, true, logp_all, value, hidden_out);   // feat == h' after the GRU
+    return r;
+}
 int mi_forward(mi_ctx* c, const void* obs, int32_t n, float* logp_all, float* value, float* feat) {
+    return forward_common(c, obs, n, false, logp_all, value, feat);
+}
+static int forward_common(mi_ctx* c, const void* obs, int32_t n, bool recurrent, float* logp_all, float* value, float* feat) {
     ARG(c && obs, "null"); ARG(n >= 1 && n <= c->NB, "n must be in [1, max_batch]");
     c->staged_valid = false;
     void* stage = c->stage_frames ? (void*)c->stage_frames : (void*)c->stage_obs;
     HIPC(hipMemcpyAsync(stage, obs, (size_t)n * c->obs_bytes_per_env, hipMemcpyHostToDevice, c->stream));
     InputSrc src{stage, nullptr, 0};
-    net_forward(c, src, n);
+    net_forward(c, src, n, recurrent);
     launch_logp_all(c->hout, n, c->A, c->d_lp, nullptr, c->stream);
     HIPC(hipGetLastError());
     if (logp_all) HIPC(hipMemcpyAsync(logp_all, c->d_lp, (size_t)n * c->A * 4, hipMemcpyDeviceToHost, c->stream));

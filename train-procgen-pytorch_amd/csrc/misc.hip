@@ -602,3 +602,33 @@ void launch_adam(float* p, float* g, float* m, float* v, long long n, const doub
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, sumsq, max_norm, lr,
                        beta1, beta2, eps, step_size, bc2_sqrt, gnorm_out);
 }
+
+// ------------------------------------------------------------------------------------------ GRU cell (rollout only)
+// nn.GRU single step (common/model.py:219-225): gi = W_ih x + b_ih, gh = W_hh (h*mask) + b_hh come from the GEMM;
+// r = s(gi_r+gh_r), z = s(gi_z+gh_z), n = tanh(gi_n + r*gh_n), h' = (1-z)*n + z*h.
+__global__ void mask_rows_kernel(const float* h, const float* done, float* out, int n, int H) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * H) return;
+    out[e] = h[e] * (1.f - done[e / H]);
+}
+void launch_mask_rows(const float* h, const float* done, float* out, int n, int H, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(mask_rows_kernel, dim3((n * H + 255) / 256), dim3(256), 0, st, h, done, out, n, H);
+}
+__global__ void gru_gates_kernel(const float* gi, const float* gh, const float* hm, float* h_out, float* feat_out, int n, int H) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * H) return;
+    const int row = e / H, j = e % H;
+    const float* a = gi + (long long)row * 3 * H;
+    const float* b = gh + (long long)row * 3 * H;
+    const float r = 1.f / (1.f + expf(-(a[j] + b[j])));
+    const float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
+    const float nn = tanhf(a[2 * H + j] + r * b[2 * H + j]);
+    const float hn = (1.f - z) * nn + z * hm[e];
+    h_out[e] = hn;
+    feat_out[e] = hn;
+}
+void launch_gru_gates(const float* gi, const float* gh, const float* hm, float* h_out, float* feat_out, int n, int H, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gru_gates_kernel, dim3((n * H + 255) / 256), dim3(256), 0, st, gi, gh, hm, h_out, feat_out, n, H);
+}

@@ -38,7 +38,7 @@ def lib_path():
 
 EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_param_count mi_set_params "
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
-           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_predict_staged mi_commit_staged mi_forward mi_compute_estimates "
+           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_predict_staged mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_optimizer_step mi_loss_log_read mi_device_ptr "
            "mi_set_multirank mi_minibatch_finish mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
 
@@ -205,6 +205,27 @@ class Engine:
 
     def commit_staged(self, t):
         self._chk(self.lib.mi_commit_staged(self._ctx, C.c_int32(t)))
+
+    def set_gru(self, w_ih, w_hh, b_ih, b_hh):
+        a = [_f32(x) for x in (w_ih, w_hh, b_ih, b_hh)]
+        self._chk(self.lib.mi_set_gru(self._ctx, *[_fp(x) for x in a]))
+
+    def rec_state(self, hidden=None, done=None):
+        hidden = None if hidden is None else _f32(hidden)
+        done = None if done is None else _f32(done)
+        self._chk(self.lib.mi_rec_state(self._ctx, _fp(hidden), _fp(done)))
+
+    def get_hidden(self):
+        out = np.empty((self.E, self.H), np.float32)
+        self._chk(self.lib.mi_get_hidden(self._ctx, _fp(out)))
+        return out
+
+    def forward_rec(self, obs):
+        want = np.uint8 if self.arch == ARCH_IMPALA else np.float32
+        obs = np.ascontiguousarray(obs, dtype=want)
+        lp, val, hid = np.empty((self.E, self.A), np.float32), np.empty(self.E, np.float32), np.empty((self.E, self.H), np.float32)
+        self._chk(self.lib.mi_forward_rec(self._ctx, _fp(obs), _fp(lp), _fp(val), _fp(hid)))
+        return lp, val, hid
 
     def forward(self, obs, want_feat=False):
         want = np.uint8 if self.arch == ARCH_IMPALA else np.float32

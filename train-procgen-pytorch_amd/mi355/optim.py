@@ -16,7 +16,9 @@ class DeviceAdam:
         self.policy, self.engine = policy, engine
         self._params = [p for n, p in policy.named_parameters() if not n.startswith("gru.")]
         self._names = [n for n, _ in policy.named_parameters() if not n.startswith("gru.")]
-        self._adam = optim.Adam(self._params, lr=lr, eps=eps)
+        # the container spans ALL policy parameters like the reference's optim.Adam(policy.parameters()) (a frozen GRU
+        # never receives gradients there, so it never gets optimiser state either)
+        self._adam = optim.Adam(list(policy.parameters()), lr=lr, eps=eps)
         self.step_count = 0
 
     @property
