@@ -29,11 +29,15 @@ template <int CIN_, int CINP_, int COUT_, int HW_, int TH_, int TW_, int NIMG_, 
 struct FwdCfg {
     static constexpr int CIN = CIN_, CINP = CINP_, COUT = COUT_, HW = HW_, TH = TH_, TW = TW_, NIMG = NIMG_;
     static constexpr bool IN_U8 = IN_U8_, TRANSW = TRANSW_;
-    static constexpr int S = (CINP == 4) ? 4 : CINP + 4;        // LDS floats per input pixel
+    // LDS floats per input pixel / per filter row, chosen so that every ds_read_b128 lane group (and the conv1
+    // ds_read_b32 half-waves) is bank-conflict free: pixel stride = 2*odd 16-B slots, lane quarter q at slot q
+    // (+4 slots for the second half of a 32-channel pixel) -- measured: SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE
+    // 0.46-0.50 with the naive CINP+4 stride.
+    static constexpr int S = (CINP == 4) ? 6 : (CINP == 16 ? 20 : 40);   // (CINP 16: the conflict-free 24 costs a workgroup per CU and measured slower)
     static constexpr int PH = TH + 2, PW = TW + 2;
     static constexpr int NPIX = NIMG * PH * PW;
     static constexpr int IN_FLOATS = NPIX * S;
-    static constexpr int WS = (CINP == 4) ? 37 : 9 * CINP + 4;  // LDS floats per output channel of the filter bank
+    static constexpr int WS = (CINP == 4) ? 38 : (CINP == 16 ? 148 : 296);   // LDS floats per output channel of the filter bank
     static constexpr int W_FLOATS = ((COUT * WS + 3) / 4) * 4;
     static constexpr int NMT = NIMG * TH * TW / 16;             // 16-pixel M tiles per work item
     static constexpr int MT = NMT / 4;                          // per wave
@@ -158,6 +162,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 
     const int nwork = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
     tile_clear<C>(s_in);
+    float bias_r[C::NB];
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) bias_r[nb] = a.bias ? a.bias[nb * 16 + i] : 0.f;
     TileRegs<C> regs;
     int img0, ty0, tx0;
     if ((int)blockIdx.x < nwork) {
@@ -175,6 +182,51 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             tile_load<C>(regs, a.in, a.idx, a.in_base, a.n, i2, y2, x2);
         }
 
+        // epilogue operands (ReLU-mask source, residual) are requested BEFORE the MFMA phase so that their HBM
+        // latency hides under it (issued right before use they cost a full round trip per tile)
+        // (whole load blocks sit under ONE wave-uniform branch each: a per-element "load or constant" select makes
+        //  hipcc branch and wait around every single load)
+        float e_mask[C::MT][4][C::NB], e_res[C::MT][4][C::NB];
+        long long e_off[C::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pl = (wave * C::MT + mt) * 16 + q * 4 + r, y = pl / C::TW, x = pl % C::TW;
+                int n = img0 + y / C::TH;
+                n = n < a.n ? n : a.n - 1;                           // tail of a multi-image work item: any valid address
+                e_off[mt][r] = (((long long)n * C::HW + ty0 + (y % C::TH)) * C::HW + tx0 + x) * C::COUT + i;
+            }
+        if (a.mask) {
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][r][nb] = a.mask[e_off[mt][r] + nb * 16];
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][r][nb] = 1.f;
+        }
+        if (a.res) {
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) e_res[mt][r][nb] = a.res[e_off[mt][r] + nb * 16];
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) e_res[mt][r][nb] = 0.f;
+        }
         f32x4 acc[C::MT][C::NB];
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
@@ -184,9 +236,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
             const int pl = (wave * C::MT + mt) * 16 + i, y = pl / C::TW, x = pl % C::TW;
-            abase[mt] = (((y / C::TH) * C::PH + (y % C::TH)) * C::PW + x) * C::S + q * (C::CINP / 4);
+            abase[mt] = (((y / C::TH) * C::PH + (y % C::TH)) * C::PW + x) * C::S + (C::CINP == 4 ? q : q * 4);
         }
-        const int bbase = i * C::WS + q * (C::CINP / 4);
+        const int bbase = i * C::WS + (C::CINP == 4 ? q : q * 4);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = ((tap / 3) * C::PW + (tap % 3)) * C::S;
@@ -205,10 +257,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                 for (int s4 = 0; s4 < C::CINP / 16; ++s4) {
                     f32x4 av[C::MT], bv[C::NB];
 #pragma unroll
-                    for (int mt = 0; mt < C::MT; ++mt) av[mt] = *(const f32x4*)(s_in + abase[mt] + toff + s4 * 4);
+                    for (int mt = 0; mt < C::MT; ++mt) av[mt] = *(const f32x4*)(s_in + abase[mt] + toff + s4 * 16);
 #pragma unroll
                     for (int nb = 0; nb < C::NB; ++nb)
-                        bv[nb] = *(const f32x4*)(s_w + bbase + nb * 16 * C::WS + tap * C::CINP + s4 * 4);
+                        bv[nb] = *(const f32x4*)(s_w + bbase + nb * 16 * C::WS + tap * C::CINP + s4 * 16);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -232,10 +284,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                     for (int nb = 0; nb < C::NB; ++nb) {
                         const int co = nb * 16 + i;
                         const long long o = gp * C::COUT + co;
-                        float v = acc[mt][nb][r];
-                        if (a.bias) v += a.bias[co];
-                        if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
-                        if (a.res) v += a.res[o];
+                        float v = acc[mt][nb][r] + bias_r[nb];
+                        v = e_mask[mt][r][nb] > 0.f ? v : 0.f;
+                        v += e_res[mt][r][nb];
                         a.out[o] = v;
                     }
                 }
