@@ -29,6 +29,7 @@ import yaml
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: matrix fp32 (v_mfma_f32_*_f32), dense
+MFMA_BF16_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: bf16 MFMA, dense (the 5 PF headline is 2:1 sparse)
 
 
 def cpu_baseline(T, n_samples, threads):
@@ -91,6 +92,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="activation storage: fp32 = parity mode; bf16 = BASELINE config 3 (bf16 storage + bf16 MFMA fwd/dgrad)")
+    ap.add_argument("--profile-rollout", action="store_true", help="bracket the rollout-phase launches with HIP events too")
     ap.add_argument("--h2d", action="store_true", help="also upload the E frames of every rollout step from pinned host memory")
     args = ap.parse_args()
 
@@ -122,7 +126,7 @@ def main():
     class _Log:
         episode_reward_buffer = [0.0]
         logdir = "/tmp"
-    agent = PPO(None, policy, _Log(), storage, device, 1, seed=rank, **hp)
+    agent = PPO(None, policy, _Log(), storage, device, 1, seed=rank, precision=args.precision, **hp)
     eng = agent.engine
 
     rng = np.random.default_rng(rank)
@@ -159,7 +163,7 @@ def main():
 
     for it in range(args.warmup):
         iteration(it)
-    eng.profile_enable(True)
+    eng.profile_enable(2 if args.profile_rollout else 1)
     eng.profile_read(reset=True)
     fence()
     t0 = time.perf_counter()
@@ -172,7 +176,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     prof = eng.profile_read(reset=True)
-    eng.profile_enable(False)
+    eng.profile_enable(0)
 
     if rank == 0:
         steps_total = world * T * E * args.steps
@@ -183,16 +187,20 @@ def main():
         if dom is not None:
             sec = dom["ms"] / 1e3
             gbs, tfs = dom["bytes"] / sec / 1e9, dom["flops"] / sec / 1e12
-            f_h, f_m = gbs / HBM_PEAK_GBS, tfs / MFMA_F32_PEAK_TF
+            # matrix peak of the instruction this kernel issues: weight gradients and block1.conv stay on the fp32
+            # MFMA in both modes; the bf16 mode's forward / dgrad convs run v_mfma_f32_16x16x32_bf16
+            on_bf16_mfma = args.precision == "bf16" and ("wgrad" not in dom["kernel"]) and ("3_16_64" not in dom["kernel"])
+            mpeak = MFMA_BF16_PEAK_TF if on_bf16_mfma else MFMA_F32_PEAK_TF
+            f_h, f_m = gbs / HBM_PEAK_GBS, tfs / mpeak
             bound = "mfma" if f_m >= f_h else "hbm"
-            roof = dict(bound=bound, achieved=(tfs if bound == "mfma" else gbs), peak=(MFMA_F32_PEAK_TF if bound == "mfma" else HBM_PEAK_GBS),
+            roof = dict(bound=bound, achieved=(tfs if bound == "mfma" else gbs), peak=(mpeak if bound == "mfma" else HBM_PEAK_GBS),
                         unit=("TFLOP/s" if bound == "mfma" else "GB/s"), frac=(f_m if bound == "mfma" else f_h), traffic=None,
                         kernel=dom["kernel"], avg_launch_ms=dom["ms"] / dom["launches"], launches=dom["launches"],
                         samples_per_launch=dom["samples"] / dom["launches"], hbm_GBps=gbs, hbm_frac=f_h, mfma_TFps=tfs, mfma_frac=f_m,
                         share_of_timed_region=dom["ms"] / 1e3 / dt)
         out = {"metric": "env steps/sec (whole node), coinrun hard-500 IMPALA-CNN PPO", "value": value, "unit": "env steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if args.precision == "bf16" else "f32"), "data": "synthetic",
                "config": {"workload": f"PPO iteration, {args.param_name}: IMPALA-CNN, T={T}, E={E} envs per GPU, "
                                       f"{hp['epoch']} epochs x {hp['n_minibatch']} minibatches of {agent.mini_batch_size} (global), "
                                       f"A={A}, frames resident in HBM" + (" + per-step H2D" if args.h2d else ""),

@@ -35,7 +35,10 @@ typedef struct mi_config {
     int32_t out_dim;       /* embedder.output_dim: 256 for IMPALA, latent_size for MLP */
     int32_t max_batch;     /* largest number of samples one mi_minibatch / mi_forward call may carry */
     int32_t device;        /* HIP device ordinal */
-    int32_t reserved[6];
+    int32_t precision;     /* IMPALA activations / activation gradients in HBM: 0 = fp32 (parity mode), 1 = bf16 storage +
+                              bf16 matrix cores with fp32 accumulation for the 16/32-channel convs (BASELINE config 3);
+                              parameters, gradients of parameters, Adam, losses and GAE are fp32 in both modes */
+    int32_t reserved[5];
     void*   stream;        /* hipStream_t to issue on, or NULL for a stream owned by the context */
 } mi_config;
 
@@ -133,7 +136,7 @@ int mi_minibatch_finish(mi_ctx* ctx);      /* multirank only: phase 2 + backward
  *      update phase (phase 1, n = minibatch).  mi_profile_read fills up to max_rows rows of
  *      {class id, phase, launches, total ms, total samples, total algorithmic bytes, total algorithmic flops}
  *      (layer-boundary model of SURVEY.md 8(d)); names via mi_profile_class_name. */
-int mi_profile_enable(mi_ctx* ctx, int32_t enabled);
+int mi_profile_enable(mi_ctx* ctx, int32_t enabled);   /* 0 off, 1 update phase only, 2 rollout + update */
 int mi_profile_read(mi_ctx* ctx, double* rows7, int32_t max_rows, int32_t* n_rows, int32_t reset);
 const char* mi_profile_class_name(int32_t class_id);
 

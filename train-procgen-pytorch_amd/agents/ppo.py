@@ -44,6 +44,8 @@ class PPO(BaseAgent):
         self.normalize_adv, self.normalize_rew, self.use_gae = normalize_adv, normalize_rew, use_gae
         self.adjust_lr = adjust_lr_grok if increasing_lr else adjust_lr
         self.seed = int(kwargs.get("seed", 0))
+        # activation storage of the IMPALA path: "fp32" (parity mode) or "bf16" (BASELINE config 3)
+        self.precision = kwargs.get("precision", "fp32") if policy.arch == "impala" else "fp32"
 
         # ---- data parallel over n_envs: this process owns n_envs envs; the global minibatch spans all ranks
         self.coll = Collective()
@@ -59,7 +61,8 @@ class PPO(BaseAgent):
         self.engine = Engine(arch, n_steps, n_envs, policy.action_size, max_batch=max(max_local, n_envs),
                              obs_dim=getattr(emb, "input_size", 0), mlp_depth=getattr(emb, "depth", 0),
                              mlp_width=getattr(emb, "mid_weight", 0), out_dim=emb.output_dim, device=dev_index,
-                             stream=self._tstream.cuda_stream if self._tstream is not None else None)
+                             stream=self._tstream.cuda_stream if self._tstream is not None else None,
+                             precision=self.precision)
         policy.attach_engine(self.engine)
         storage.attach_engine(self.engine)
         self.engine_valid = None
@@ -67,7 +70,8 @@ class PPO(BaseAgent):
             # inference-only twin for the validation rollouts (shares nothing but the weights it is handed)
             self.engine_valid = Engine(arch, n_steps, n_envs, policy.action_size, max_batch=n_envs,
                                        obs_dim=getattr(emb, "input_size", 0), mlp_depth=getattr(emb, "depth", 0),
-                                       mlp_width=getattr(emb, "mid_weight", 0), out_dim=emb.output_dim, device=dev_index)
+                                       mlp_width=getattr(emb, "mid_weight", 0), out_dim=emb.output_dim, device=dev_index,
+                                       precision=self.precision)
             storage_valid.attach_engine(self.engine_valid)
             if policy.is_recurrent():
                 g = policy.gru.gru

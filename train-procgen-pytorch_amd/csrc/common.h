@@ -17,23 +17,25 @@ struct ConvArgs {
     long long      in_base;   // u8 input only: first frame when idx == null (rollout step t -> t*E)
     const float*   w;         // device weight layout [CO][9][CI] (tap = ky*3+kx), CO/CI of the FORWARD conv
     const float*   bias;      // [COUT] or null
-    const float*   res;       // optional residual, same shape as out: out += res
-    const float*   mask;      // optional ReLU mask source, same shape as out: out *= (mask > 0)
-    float*         out;       // fp32 NHWC [n][HW][HW][COUT]
+    const void*    res;       // optional residual, same shape / type as out: out += res
+    const void*    mask;      // optional ReLU mask source, same shape / type as out: out *= (mask > 0)
+    void*          out;       // NHWC [n][HW][HW][COUT], fp32 or bf16
     const float*   lut;       // 256-entry u8 -> fp32 table (k/255 correctly rounded)
     int            n;         // images
     int            relu_in;   // apply max(x,0) while staging the input tile
+    int            bf16;      // activations (in/res/mask/out) are bf16 in HBM
 };
 
 struct WgradArgs {
     const void*    in;        // forward input of the conv (fp32 NHWC or u8 frames)
     const int32_t* idx;
     long long      in_base;
-    const float*   dout;      // fp32 NHWC [n][HW][HW][COUT]
+    const void*    dout;      // NHWC [n][HW][HW][COUT], fp32 or bf16
     float*         partial;   // [gridDim.x][COUT*9*CIN + COUT] per-workgroup slabs (weights then bias)
     const float*   lut;
     int            n;
     int            relu_in;
+    int            bf16;      // in (unless uint8 frames) and dout are bf16 in HBM
 };
 
 enum ConvShape {              // (CIN, COUT, HW) of the FORWARD conv
@@ -51,6 +53,11 @@ void launch_conv_dgrad(ConvShape s, const ConvArgs& a, hipStream_t st);   // a.i
 int  wgrad_grid(ConvShape s, int n);                                       // workgroups a wgrad launch will use
 void launch_conv_wgrad(ConvShape s, const WgradArgs& a, hipStream_t st);
 void conv_shape_dims(ConvShape s, int* cin, int* cout, int* hw);
+void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st);     // conv_bf16.hip (bf16 MFMA)
+void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st);
+int  wgrad_grid_bf16(ConvShape s, int n);                                  // -1: shape handled by conv.hip
+void launch_conv_wgrad_bf16(ConvShape s, const WgradArgs& a, hipStream_t st);
+int  wgrad_grid_for(ConvShape s, int n, int bf16);                          // slabs a wgrad launch writes
 
 // ---------------------------------------------------------------- generic MFMA GEMM (linear layers)
 // C[M][N] (op)= sum_k A(m,k) * B(k,n);  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].
@@ -63,12 +70,15 @@ struct GemmArgs {
     int relu_a, relu_b;    // max(x,0) on operand load
     int relu_out;          // max(c,0) in the epilogue (after bias)
     int accumulate;        // C += result
+    int a_bf16, b_bf16, mask_bf16, c_bf16;   // the operand / mask / output is bf16 in HBM (arithmetic stays fp32)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);
 
 // ---------------------------------------------------------------- small kernels (misc.hip)
 void launch_maxpool_fwd(const float* in, float* out, uint8_t* arg, int n, int hw, int c, hipStream_t st);
 void launch_maxpool_bwd(const float* dout, const uint8_t* arg, float* din, int n, int hw, int c, hipStream_t st);
+void launch_maxpool_fwd_bf16(const void* in, void* out, uint8_t* arg, int n, int hw, int c, hipStream_t st);
+void launch_maxpool_bwd_bf16(const void* dout, const uint8_t* arg, void* din, int n, int hw, int c, hipStream_t st);
 void launch_reduce_slabs(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b,
                          hipStream_t st);
 void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, hipStream_t st);
@@ -95,7 +105,7 @@ void launch_logp_all(const float* hout, int n, int A, float* lp_out, float* valu
 void gemm_set_workspace(float* ws, size_t floats);
 void colsum_set_workspace(float* ws);   // >= 64 * max_N floats
 void launch_loss_bwd(const LossArgs& a, hipStream_t st);
-void launch_fs_metric(const float* flat_pre, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st);
+void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st);
 
 void launch_gae(const float* rew, const float* done, const float* value, float* adv, float* ret, int T, int E,
                 float gamma, float lmbda, int use_gae, hipStream_t st);

@@ -25,10 +25,11 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int CIN_, int CINP_, int COUT_, int HW_, int TH_, int TW_, int NIMG_, bool IN_U8_, bool TRANSW_>
+template <int CIN_, int CINP_, int COUT_, int HW_, int TH_, int TW_, int NIMG_, bool IN_U8_, bool TRANSW_, bool BFIO_ = false>
 struct FwdCfg {
     static constexpr int CIN = CIN_, CINP = CINP_, COUT = COUT_, HW = HW_, TH = TH_, TW = TW_, NIMG = NIMG_;
     static constexpr bool IN_U8 = IN_U8_, TRANSW = TRANSW_;
+    static constexpr bool BFIO = BFIO_;     // activations in HBM are bf16 (fp32 arithmetic inside the kernel)
     // LDS floats per input pixel / per filter row, chosen so that every ds_read_b128 lane group (and the conv1
     // ds_read_b32 half-waves) is bank-conflict free: pixel stride = 2*odd 16-B slots, lane quarter q at slot q
     // (+4 slots for the second half of a 32-channel pixel) -- measured: SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE
@@ -51,10 +52,20 @@ struct FwdCfg {
 // Input-tile staging is split in two so that the HBM latency of tile i+1 hides under the MFMAs of tile i
 // (issue-early / write-late): tile_load puts the next tile's global loads in flight into registers before the
 // compute phase, tile_store converts (uint8 -> fp32 table / ReLU) and writes them to LDS after it.
+__device__ __forceinline__ unsigned short f2bf(float x) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+template <bool BF> __device__ __forceinline__ float ld_act(const void* p, long long o) {
+    if constexpr (BF) return bf2f(((const unsigned short*)p)[o]); else return ((const float*)p)[o];
+}
+template <bool BF> __device__ __forceinline__ void st_act(void* p, long long o, float v) {
+    if constexpr (BF) ((unsigned short*)p)[o] = f2bf(v); else ((float*)p)[o] = v;
+}
+
 template <class C>
 struct TileRegs {
-    static constexpr int C4 = C::CINP / 4;
-    // fp32: 16-byte chunks of the haloed tile;  uint8: the tile's full-width rows as dwords (HW*3/4 per row)
+    // fp32: 16-byte chunks of 4 channels;  bf16: 16-byte chunks of 8 channels;
+    // uint8: the tile's full-width rows as dwords (HW*3/4 per row)
+    static constexpr int C4 = C::BFIO ? C::CINP / 8 : C::CINP / 4;      // 16-byte chunks per pixel
     static constexpr int ROW_DW = C::HW * 3 / 4;
     static constexpr int N = C::IN_U8 ? (C::NIMG * C::PH * ROW_DW + 255) / 256 : (C::NPIX * C4 + 255) / 256;
     f32x4 v[C::IN_U8 ? 1 : N];
@@ -92,7 +103,7 @@ __device__ __forceinline__ void tile_load(TileRegs<C>& r, const void* in, const 
                 const int img = pix / (C::PH * C::PW), q = pix % (C::PH * C::PW);
                 const int gy = ty0 + q / C::PW - 1, gx = tx0 + q % C::PW - 1, n = img0 + img;
                 if (n < n_img && gy >= 0 && gy < C::HW && gx >= 0 && gx < C::HW)
-                    v = *(const f32x4*)((const float*)in + (((long long)n * C::HW + gy) * C::HW + gx) * C::CIN + c4 * 4);
+                    v = *(const f32x4*)((const char*)in + ((((long long)n * C::HW + gy) * C::HW + gx) * C::CIN * (C::BFIO ? 2 : 4) + c4 * 16));
             }
             r.v[k] = v;
         }
@@ -123,9 +134,22 @@ __device__ __forceinline__ void tile_store(const TileRegs<C>& r, float* s_in, co
         for (int k = 0; k < TileRegs<C>::N; ++k) {
             const int e = tid + k * 256;
             if (e < C::NPIX * C4) {
-                f32x4 v = r.v[k];
-                if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *(f32x4*)(s_in + (e / C4) * C::S + (e % C4) * 4) = v;
+                if constexpr (C::BFIO) {                       // 8 bf16 -> 8 fp32 (two 4-channel chunks of the fp32 tile)
+                    const uint4 u = __builtin_bit_cast(uint4, r.v[k]);
+                    f32x4 lo = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+                    f32x4 hi = {__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+                    if (relu_in) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { lo[c] = fmaxf(lo[c], 0.f); hi[c] = fmaxf(hi[c], 0.f); }
+                    }
+                    float* d = s_in + (e / C4) * C::S + (e % C4) * 8;
+                    *(f32x4*)d = lo;
+                    *(f32x4*)(d + 4) = hi;
+                } else {
+                    f32x4 v = r.v[k];
+                    if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *(f32x4*)(s_in + (e / C4) * C::S + (e % C4) * 4) = v;
+                }
             }
         }
     }
@@ -203,7 +227,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][r][nb] = a.mask[e_off[mt][r] + nb * 16];
+                    for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][r][nb] = ld_act<C::BFIO>(a.mask, e_off[mt][r] + nb * 16);
         } else {
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) e_res[mt][r][nb] = a.res[e_off[mt][r] + nb * 16];
+                    for (int nb = 0; nb < C::NB; ++nb) e_res[mt][r][nb] = ld_act<C::BFIO>(a.res, e_off[mt][r] + nb * 16);
         } else {
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
@@ -287,7 +311,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                         float v = acc[mt][nb][r] + bias_r[nb];
                         v = e_mask[mt][r][nb] > 0.f ? v : 0.f;
                         v += e_res[mt][r][nb];
-                        a.out[o] = v;
+                        st_act<C::BFIO>(a.out, o, v);
                     }
                 }
             }
@@ -295,10 +319,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
-template <int CIN_, int CINP_, int COUT_, int HW_, int TH_, int TW_, int NIMG_, bool IN_U8_>
+template <int CIN_, int CINP_, int COUT_, int HW_, int TH_, int TW_, int NIMG_, bool IN_U8_, bool BFIO_ = false>
 struct WgCfg {
     static constexpr int CIN = CIN_, CINP = CINP_, COUT = COUT_, HW = HW_, TH = TH_, TW = TW_, NIMG = NIMG_;
-    static constexpr bool IN_U8 = IN_U8_, TRANSW = false;
+    static constexpr bool IN_U8 = IN_U8_, TRANSW = false, BFIO = BFIO_;
     static constexpr int S = (CINP == 4) ? 4 : (CINP == 32 ? 48 : 16);   // input pixel stride in LDS
     static constexpr int SO = (COUT == 32) ? 48 : 16;                    // dOut pixel stride in LDS
     static constexpr int PH = TH + 2, PW = TW + 2;
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     const int nwork = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
     tile_clear<C>(s_in);
     TileRegs<C> regs;
-    constexpr int OC4 = C::COUT / 4, NDO = (C::NT * OC4 + 255) / 256;
+    constexpr int OC4 = C::BFIO ? C::COUT / 8 : C::COUT / 4, NDO = (C::NT * OC4 + 255) / 256;     // 16-byte chunks
     f32x4 dreg[NDO];
     auto dout_load = [&](int i0, int y0, int x0) {
 #pragma unroll
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             if (e < C::NT * OC4) {
                 const int pl = e / OC4, c4 = e % OC4, y = pl / C::TW, x = pl % C::TW, n = i0 + y / C::TH;
                 if (n < a.n)
-                    v = *(const f32x4*)(a.dout + (((long long)n * C::HW + y0 + (y % C::TH)) * C::HW + x0 + x) * C::COUT + c4 * 4);
+                    v = *(const f32x4*)((const char*)a.dout + ((((long long)n * C::HW + y0 + (y % C::TH)) * C::HW + x0 + x) * C::COUT * (C::BFIO ? 2 : 4) + c4 * 16));
             }
             dreg[k] = v;
         }
@@ -370,7 +394,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int k = 0; k < NDO; ++k) {
             const int e = tid + k * 256;
-            if (e < C::NT * OC4) *(f32x4*)(s_do + (e / OC4) * C::SO + (e % OC4) * 4) = dreg[k];
+            if (e < C::NT * OC4) {
+                if constexpr (C::BFIO) {
+                    const uint4 u = __builtin_bit_cast(uint4, dreg[k]);
+                    float* d = s_do + (e / OC4) * C::SO + (e % OC4) * 8;
+                    *(f32x4*)d = (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+                    *(f32x4*)(d + 4) = (f32x4){__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+                } else {
+                    *(f32x4*)(s_do + (e / OC4) * C::SO + (e % OC4) * 4) = dreg[k];
+                }
+            }
         }
         __syncthreads();
         if (work + (int)gridDim.x < nwork) {
@@ -471,6 +504,13 @@ using W_16_16_32  = WgCfg<16, 16, 16, 32, 8, 32, 1, false>;
 using W_16_32_32  = WgCfg<16, 16, 32, 32, 8, 32, 1, false>;
 using W_32_32_16  = WgCfg<32, 32, 32, 16, 8, 16, 1, false>;
 using W_32_32_8   = WgCfg<32, 32, 32,  8, 8,  8, 2, false>;
+// bf16 activation storage, fp32 arithmetic: block1.conv forward (uint8 in, bf16 out) and every weight gradient
+using FB_3_16_64  = FwdCfg< 3,  4, 16, 64, 8, 64, 1, true,  false, true>;
+using WB_3_16_64  = WgCfg< 3,  4, 16, 64, 8, 64, 1, true,  true>;
+using WB_16_16_32 = WgCfg<16, 16, 16, 32, 8, 32, 1, false, true>;
+using WB_16_32_32 = WgCfg<16, 16, 32, 32, 8, 32, 1, false, true>;
+using WB_32_32_16 = WgCfg<32, 32, 32, 16, 8, 16, 1, false, true>;
+using WB_32_32_8  = WgCfg<32, 32, 32,  8, 8,  8, 2, false, true>;
 
 // persistent grids: as many workgroups per CU as the LDS footprint admits (max 4), on a 256-CU part
 template <class C>
@@ -505,6 +545,10 @@ void conv_shape_dims(ConvShape s, int* cin, int* cout, int* hw) {
 }
 
 void launch_conv_fwd(ConvShape s, const ConvArgs& a, hipStream_t st) {
+    if (a.bf16) {
+        if (s == CS_3_16_64) launch_fwd_t<FB_3_16_64>(a, st); else launch_conv_fwd_bf16(s, a, st);
+        return;
+    }
     switch (s) {
         case CS_3_16_64:  launch_fwd_t<F_3_16_64>(a, st); break;
         case CS_16_16_32: launch_fwd_t<F_16_16_32>(a, st); break;
@@ -516,6 +560,7 @@ void launch_conv_fwd(ConvShape s, const ConvArgs& a, hipStream_t st) {
 }
 
 void launch_conv_dgrad(ConvShape s, const ConvArgs& a, hipStream_t st) {
+    if (a.bf16) { launch_conv_dgrad_bf16(s, a, st); return; }
     switch (s) {
         case CS_16_16_32: launch_fwd_t<D_16_16_32>(a, st); break;
         case CS_16_32_32: launch_fwd_t<D_16_32_32>(a, st); break;
@@ -538,7 +583,24 @@ int wgrad_grid(ConvShape s, int n) {
     }
 }
 
+int wgrad_grid_for(ConvShape s, int n, int bf16) {
+    if (bf16) { const int g = wgrad_grid_bf16(s, n); if (g >= 0) return g; return wg_grid_t<WB_3_16_64>(n); }
+    return wgrad_grid(s, n);
+}
+
 void launch_conv_wgrad(ConvShape s, const WgradArgs& a, hipStream_t st) {
+    if (a.bf16) {
+        if (wgrad_grid_bf16(s, a.n) >= 0) { launch_conv_wgrad_bf16(s, a, st); return; }
+        switch (s) {
+            case CS_3_16_64:  launch_wg_t<WB_3_16_64>(a, st); break;
+            case CS_16_16_32: launch_wg_t<WB_16_16_32>(a, st); break;
+            case CS_16_32_32: launch_wg_t<WB_16_32_32>(a, st); break;
+            case CS_32_32_16: launch_wg_t<WB_32_32_16>(a, st); break;
+            case CS_32_32_8:  launch_wg_t<WB_32_32_8>(a, st); break;
+            default: break;
+        }
+        return;
+    }
     switch (s) {
         case CS_3_16_64:  launch_wg_t<W_3_16_64>(a, st); break;
         case CS_16_16_32: launch_wg_t<W_16_16_32>(a, st); break;

@@ -1,0 +1,450 @@
+// bf16 storage / bf16 matrix-core variant of the 3x3 convolutions (forward + data gradient) for the 16- and
+// 32-channel layers of the IMPALA-CNN (BASELINE config 3: "IMPALA-CNN bf16").  Activations and activation
+// gradients live in HBM as bf16 NHWC (half the bytes of the fp32 path); the fp32 master weights are rounded to
+// bf16 while the filter bank is staged into LDS; products accumulate in fp32 (v_mfma_f32_16x16x32_bf16);
+// bias / ReLU-mask / residual are applied in fp32 and the result is rounded to bf16 once, at the store.
+//
+// Same decomposition as conv.hip (persistent workgroups, register-prefetched haloed tiles, epilogue operands
+// requested before the MFMA phase).  One MFMA consumes K = 32: for 32 input channels that is one filter tap
+// (lane quarter kq owns channels 8kq..8kq+7); for 16 input channels it is two taps (kq>>1 selects the tap,
+// kq&1 the 8-channel half), the 10th "tap" being a zero column of the filter bank.
+#include "common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned short f2bf(float x) {
+    __bf16 h = (__bf16)x;                                   // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+template <int CIN_, int COUT_, int HW_, int TH_, int TW_, int NIMG_, bool TRANSW_>
+struct BfCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, HW = HW_, TH = TH_, TW = TW_, NIMG = NIMG_;
+    static constexpr bool TRANSW = TRANSW_;
+    static constexpr int S = CIN + 8;                        // bf16 elements per staged pixel (16-B aligned rows)
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int NPIX = NIMG * PH * PW;
+    static constexpr int IN_ELEMS = ((NPIX * S + 7) / 8) * 8;
+    static constexpr int NK = (CIN == 32) ? 9 : 5;           // MFMAs (K = 32 each) per (pixel tile, channel block)
+    static constexpr int WS = NK * 32 + 8;                   // bf16 elements per output channel of the filter bank
+    static constexpr int W_ELEMS = COUT * WS;
+    static constexpr int NMT = NIMG * TH * TW / 16, MT = NMT / 4, NB = COUT / 16;
+    static constexpr int TPI_X = HW / TW, TPI = (HW / TH) * (HW / TW);
+    static constexpr int C8 = CIN / 8;
+    static constexpr int NLD = (NPIX * C8 + 255) / 256;
+    static constexpr size_t LDS_BYTES = (size_t)(IN_ELEMS + W_ELEMS) * 2;
+    static_assert(NMT % 4 == 0, "M tiles must split over 4 waves");
+};
+
+template <class C>
+__device__ __forceinline__ void bf_coords(int work, int& img0, int& ty0, int& tx0) {
+    if (C::NIMG > 1) { img0 = work * C::NIMG; ty0 = 0; tx0 = 0; }
+    else { img0 = work / C::TPI; const int t = work % C::TPI; ty0 = (t / C::TPI_X) * C::TH; tx0 = (t % C::TPI_X) * C::TW; }
+}
+
+template <class C>
+__device__ __forceinline__ void bf_tile_load(uint4 (&r)[C::NLD], const unsigned short* in, int n_img, int img0, int ty0, int tx0) {
+#pragma unroll
+    for (int k = 0; k < C::NLD; ++k) {
+        const int e = threadIdx.x + k * 256;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (e < C::NPIX * C::C8) {
+            const int pix = e / C::C8, c8 = e % C::C8;
+            const int img = pix / (C::PH * C::PW), q = pix % (C::PH * C::PW);
+            const int gy = ty0 + q / C::PW - 1, gx = tx0 + q % C::PW - 1, n = img0 + img;
+            if (n < n_img && gy >= 0 && gy < C::HW && gx >= 0 && gx < C::HW)
+                v = *(const uint4*)(in + (((long long)n * C::HW + gy) * C::HW + gx) * C::CIN + c8 * 8);
+        }
+        r[k] = v;
+    }
+}
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned w) {         // zero every 16-bit lane whose sign bit is set
+    const unsigned neg = (w >> 15) & 0x00010001u;
+    return w & ~(neg * 0xFFFFu);
+}
+template <class C>
+__device__ __forceinline__ void bf_tile_store(const uint4 (&r)[C::NLD], unsigned short* s_in, int relu_in) {
+#pragma unroll
+    for (int k = 0; k < C::NLD; ++k) {
+        const int e = threadIdx.x + k * 256;
+        if (e < C::NPIX * C::C8) {
+            uint4 v = r[k];
+            if (relu_in) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+            *(uint4*)(s_in + (e / C::C8) * C::S + (e % C::C8) * 8) = v;
+        }
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_in = smem_h;
+    unsigned short* s_w = smem_h + C::IN_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const unsigned short* g_in = (const unsigned short*)a.in;
+    const unsigned short* g_mask = (const unsigned short*)a.mask;
+    const unsigned short* g_res = (const unsigned short*)a.res;
+    unsigned short* g_out = (unsigned short*)a.out;
+
+    // filter bank -> LDS [co][tap-major K][ci] in bf16 (dgrad: co<->ci swapped, taps mirrored); K padded with zeros
+    for (int e = tid; e < C::COUT * C::WS; e += 256) {
+        const int j = e / C::WS, k = e % C::WS;
+        float v = 0.f;
+        const int tap = k / C::CIN, ci = k % C::CIN;
+        if (k < C::NK * 32 && tap < 9) v = C::TRANSW ? a.w[(ci * 9 + (8 - tap)) * C::COUT + j] : a.w[(j * 9 + tap) * C::CIN + ci];
+        s_w[e] = f2bf(v);
+    }
+
+    float bias_r[C::NB];
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) bias_r[nb] = a.bias ? a.bias[nb * 16 + i] : 0.f;
+    // per-lane A offsets of the NK K-steps: tap offset + 8-channel chunk
+    int koff[C::NK];
+#pragma unroll
+    for (int m = 0; m < C::NK; ++m) {
+        int tap, chunk;
+        if (C::CIN == 32) { tap = m; chunk = kq; } else { tap = 2 * m + (kq >> 1); chunk = kq & 1; if (tap > 8) tap = 8; }
+        koff[m] = ((tap / 3) * C::PW + (tap % 3)) * C::S + chunk * 8;
+    }
+
+    const int nwork = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
+    uint4 regs[C::NLD];
+    int img0, ty0, tx0;
+    if ((int)blockIdx.x < nwork) { bf_coords<C>(blockIdx.x, img0, ty0, tx0); bf_tile_load<C>(regs, g_in, a.n, img0, ty0, tx0); }
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        bf_coords<C>(work, img0, ty0, tx0);
+        __syncthreads();
+        bf_tile_store<C>(regs, s_in, a.relu_in);
+        __syncthreads();
+        if (work + (int)gridDim.x < nwork) {
+            int i2, y2, x2;
+            bf_coords<C>(work + gridDim.x, i2, y2, x2);
+            bf_tile_load<C>(regs, g_in, a.n, i2, y2, x2);
+        }
+        // epilogue operands requested before the MFMA phase (one wave-uniform branch per block of loads)
+        unsigned short e_mask[C::MT][4][C::NB], e_res[C::MT][4][C::NB];
+        long long e_off[C::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pl = (wave * C::MT + mt) * 16 + kq * 4 + r, y = pl / C::TW, x = pl % C::TW;
+                int n = img0 + y / C::TH;
+                n = n < a.n ? n : a.n - 1;
+                e_off[mt][r] = (((long long)n * C::HW + ty0 + (y % C::TH)) * C::HW + tx0 + x) * C::COUT + i;
+            }
+        if (g_mask) {
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][r][nb] = g_mask[e_off[mt][r] + nb * 16];
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][r][nb] = 0x3f80;      // 1.0
+        }
+        if (g_res) {
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) e_res[mt][r][nb] = g_res[e_off[mt][r] + nb * 16];
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) e_res[mt][r][nb] = 0;
+        }
+
+        f32x4 acc[C::MT][C::NB];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int abase[C::MT];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+            const int pl = (wave * C::MT + mt) * 16 + i, y = pl / C::TW, x = pl % C::TW;
+            abase[mt] = (((y / C::TH) * C::PH + (y % C::TH)) * C::PW + x) * C::S;
+        }
+        const int bbase = i * C::WS + kq * 8;
+#pragma unroll
+        for (int m = 0; m < C::NK; ++m) {
+            bf16x8 av[C::MT], bv[C::NB];
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) av[mt] = *(const bf16x8*)(s_in + abase[mt] + koff[m]);
+#pragma unroll
+            for (int nb = 0; nb < C::NB; ++nb) bv[nb] = *(const bf16x8*)(s_w + bbase + nb * 16 * C::WS + m * 32);
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(av[mt], bv[nb], acc[mt][nb]);
+        }
+
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pl = (wave * C::MT + mt) * 16 + kq * 4 + r, y = pl / C::TW;
+                if (img0 + y / C::TH < a.n) {
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) {
+                        float v = acc[mt][nb][r] + bias_r[nb];
+                        v = bf2f(e_mask[mt][r][nb]) > 0.f ? v : 0.f;
+                        v += bf2f(e_res[mt][r][nb]);
+                        g_out[e_off[mt][r] + nb * 16] = f2bf(v);
+                    }
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient (bf16)
+// dW[co][tap][ci] = sum over pixels dOut[p][co] * relu?(in[p + tap][ci]) on v_mfma_f32_16x16x32_bf16:
+// M = 16 output channels, N = 16 input channels, K = 32 pixels per instruction.  Both operands are K(=pixel)-major
+// while the staged tiles are [pixel][channel]: the fragments come through ds_read_b64_tr_b16 (the LDS transpose
+// read), two per operand per MFMA.  Accumulators (one 16x16 tile per tap / co-block / ci-block) stay in registers
+// across the persistent loop; waves are summed through LDS in fixed order; one slab per workgroup.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+template <int CIN_, int COUT_, int HW_, int TH_, int TW_, int NIMG_>
+struct WbCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, HW = HW_, TH = TH_, TW = TW_, NIMG = NIMG_;
+    static constexpr int S = CIN + 8, SO = COUT + 8;          // bf16 elements per staged pixel (input tile / dOut tile)
+    static constexpr int PH = TH + 2, PW = TW + 2, NPIX = NIMG * PH * PW, NT = NIMG * TH * TW;
+    static constexpr int IN_ELEMS = ((NPIX * S + 7) / 8) * 8, DO_ELEMS = ((NT * SO + 7) / 8) * 8;
+    static constexpr int NCB = COUT / 16, NIB = CIN / 16, NSTEP = NT / 32;
+    static constexpr int WLEN = COUT * 9 * CIN, SLAB = WLEN + COUT;
+    static constexpr int C8 = CIN / 8, OC8 = COUT / 8;
+    static constexpr int NLD = (NPIX * C8 + 255) / 256, NDO = (NT * OC8 + 255) / 256;
+    static constexpr int TPI_X = HW / TW, TPI = (HW / TH) * (HW / TW);
+    static constexpr size_t TILE_BYTES = (size_t)(IN_ELEMS + DO_ELEMS) * 2, RED_BYTES = (size_t)(WLEN + 256) * 4;
+    static constexpr size_t LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
+    static_assert(NT % 32 == 0, "pixel steps of 32");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_in = smem_h;
+    unsigned short* s_do = smem_h + C::IN_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    const unsigned short* g_in = (const unsigned short*)a.in;
+    const unsigned short* g_do = (const unsigned short*)a.dout;
+    f32x4 acc[9 * C::NCB * C::NIB];
+#pragma unroll
+    for (int k = 0; k < 9 * C::NCB * C::NIB; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int bc = tid % C::COUT, bg = tid / C::COUT;
+    constexpr int BG = 256 / C::COUT;
+
+    const int nwork = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
+    uint4 rin[C::NLD], rdo[C::NDO];
+    auto coords = [&](int work, int& img0, int& ty0, int& tx0) {
+        if (C::NIMG > 1) { img0 = work * C::NIMG; ty0 = 0; tx0 = 0; }
+        else { img0 = work / C::TPI; const int t = work % C::TPI; ty0 = (t / C::TPI_X) * C::TH; tx0 = (t % C::TPI_X) * C::TW; }
+    };
+    auto load = [&](int img0, int ty0, int tx0) {
+#pragma unroll
+        for (int k = 0; k < C::NLD; ++k) {
+            const int e = tid + k * 256;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (e < C::NPIX * C::C8) {
+                const int pix = e / C::C8, c8 = e % C::C8, img = pix / (C::PH * C::PW), q = pix % (C::PH * C::PW);
+                const int gy = ty0 + q / C::PW - 1, gx = tx0 + q % C::PW - 1, n = img0 + img;
+                if (n < a.n && gy >= 0 && gy < C::HW && gx >= 0 && gx < C::HW)
+                    v = *(const uint4*)(g_in + (((long long)n * C::HW + gy) * C::HW + gx) * C::CIN + c8 * 8);
+            }
+            rin[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < C::NDO; ++k) {
+            const int e = tid + k * 256;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (e < C::NT * C::OC8) {
+                const int pl = e / C::OC8, c8 = e % C::OC8, y = pl / C::TW, x = pl % C::TW, n = img0 + y / C::TH;
+                if (n < a.n)
+                    v = *(const uint4*)(g_do + (((long long)n * C::HW + ty0 + (y % C::TH)) * C::HW + tx0 + x) * C::COUT + c8 * 8);
+            }
+            rdo[k] = v;
+        }
+    };
+    int img0, ty0, tx0;
+    if ((int)blockIdx.x < nwork) { coords(blockIdx.x, img0, ty0, tx0); load(img0, ty0, tx0); }
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < C::NLD; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::NPIX * C::C8) {
+                uint4 v = rin[k];
+                if (a.relu_in) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
+                *(uint4*)(s_in + (e / C::C8) * C::S + (e % C::C8) * 8) = v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < C::NDO; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::NT * C::OC8) *(uint4*)(s_do + (e / C::OC8) * C::SO + (e % C::OC8) * 8) = rdo[k];
+        }
+        __syncthreads();
+        if (work + (int)gridDim.x < nwork) { coords(work + gridDim.x, img0, ty0, tx0); load(img0, ty0, tx0); }
+
+        for (int t = wave; t < C::NSTEP; t += 4) {
+            // this lane's two source rows (pixels) of the 4x16 transpose blocks: k = 8*kq + 4*h + rq
+            int drow[2], irow[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pl = 32 * t + 8 * kq + 4 * h + rq, y = pl / C::TW, x = pl % C::TW;
+                drow[h] = pl * C::SO + 4 * cp;
+                irow[h] = (((y / C::TH) * C::PH + (y % C::TH)) * C::PW + x) * C::S + 4 * cp;
+            }
+            bf16x8 av[C::NCB];
+#pragma unroll
+            for (int cb = 0; cb < C::NCB; ++cb) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + drow[0] + cb * 16));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + drow[1] + cb * 16));
+                av[cb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = ((tap / 3) * C::PW + (tap % 3)) * C::S;
+#pragma unroll
+                for (int ib = 0; ib < C::NIB; ++ib) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_in + irow[0] + toff + ib * 16));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_in + irow[1] + toff + ib * 16));
+                    const bf16x8 bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int cb = 0; cb < C::NCB; ++cb)
+                        acc[(tap * C::NCB + cb) * C::NIB + ib] = MFMA_BF16(av[cb], bv, acc[(tap * C::NCB + cb) * C::NIB + ib]);
+                }
+            }
+        }
+        for (int p = bg; p < C::NT; p += BG) bsum += bf2f(s_do[p * C::SO + bc]);
+    }
+
+    __syncthreads();
+    float* red = (float*)smem_h;
+    float* redb = red + C::WLEN;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int cb = 0; cb < C::NCB; ++cb)
+#pragma unroll
+                    for (int ib = 0; ib < C::NIB; ++ib)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int o = ((cb * 16 + kq * 4 + r) * 9 + tap) * C::CIN + ib * 16 + i;
+                            const float v = acc[(tap * C::NCB + cb) * C::NIB + ib][r];
+                            red[o] = (w == 0) ? v : red[o] + v;
+                        }
+        }
+        __syncthreads();
+    }
+    redb[tid] = bsum;
+    __syncthreads();
+    float* slab = a.partial + (long long)blockIdx.x * C::SLAB;
+    for (int e = tid; e < C::WLEN; e += 256) slab[e] = red[e];
+    if (tid < C::COUT) {
+        float sum = 0.f;
+        for (int g = 0; g < BG; ++g) sum += redb[g * C::COUT + tid];
+        slab[C::WLEN + tid] = sum;
+    }
+}
+
+//                          CIN COUT HW  TH  TW NIMG
+using WT_16_16_32 = WbCfg<16, 16, 32,  8, 32, 1>;
+using WT_16_32_32 = WbCfg<16, 32, 32,  8, 32, 1>;
+using WT_32_32_16 = WbCfg<32, 32, 16, 16, 16, 1>;
+using WT_32_32_8  = WbCfg<32, 32,  8,  8,  8, 4>;
+
+template <class C>
+static int wb_grid(int n) {
+    int bpc = (int)((160 * 1024) / C::LDS_BYTES);
+    bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
+    const int w = (C::NIMG > 1) ? (n + C::NIMG - 1) / C::NIMG : n * C::TPI;
+    return w > 256 * bpc ? 256 * bpc : w;
+}
+template <class C>
+static void launch_wb_t(const WgradArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    const int grid = wb_grid<C>(a.n);
+    if (grid < 1) return;
+    hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, st, a);
+}
+int wgrad_grid_bf16(ConvShape s, int n) {
+    switch (s) {
+        case CS_16_16_32: return wb_grid<WT_16_16_32>(n);
+        case CS_16_32_32: return wb_grid<WT_16_32_32>(n);
+        case CS_32_32_16: return wb_grid<WT_32_32_16>(n);
+        case CS_32_32_8:  return wb_grid<WT_32_32_8>(n);
+        default: return -1;      // block1.conv: fp32-arithmetic kernel of conv.hip
+    }
+}
+void launch_conv_wgrad_bf16(ConvShape s, const WgradArgs& a, hipStream_t st) {
+    switch (s) {
+        case CS_16_16_32: launch_wb_t<WT_16_16_32>(a, st); break;
+        case CS_16_32_32: launch_wb_t<WT_16_32_32>(a, st); break;
+        case CS_32_32_16: launch_wb_t<WT_32_32_16>(a, st); break;
+        case CS_32_32_8:  launch_wb_t<WT_32_32_8>(a, st); break;
+        default: break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+//                        CIN COUT HW  TH  TW NIMG transW       (CIN/COUT of the PASS)
+using B_16_16_32  = BfCfg<16, 16, 32,  8, 32, 1, false>;
+using B_16_32_32  = BfCfg<16, 32, 32,  8, 32, 1, false>;
+using B_32_32_16  = BfCfg<32, 32, 16, 16, 16, 1, false>;
+using B_32_32_8   = BfCfg<32, 32,  8,  8,  8, 4, false>;
+using BD_16_16_32 = BfCfg<16, 16, 32,  8, 32, 1, true>;
+using BD_16_32_32 = BfCfg<32, 16, 32,  8, 32, 1, true>;
+using BD_32_32_16 = BfCfg<32, 32, 16, 16, 16, 1, true>;
+using BD_32_32_8  = BfCfg<32, 32,  8,  8,  8, 4, true>;
+
+template <class C>
+static void launch_bf_t(const ConvArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    int bpc = (int)((160 * 1024) / C::LDS_BYTES);
+    bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
+    int grid = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
+    if (grid > 256 * bpc) grid = 256 * bpc;
+    if (grid < 1) return;
+    hipLaunchKernelGGL(conv3x3_bf16_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, st, a);
+}
+
+void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
+    switch (s) {
+        case CS_16_16_32: launch_bf_t<B_16_16_32>(a, st); break;
+        case CS_16_32_32: launch_bf_t<B_16_32_32>(a, st); break;
+        case CS_32_32_16: launch_bf_t<B_32_32_16>(a, st); break;
+        case CS_32_32_8:  launch_bf_t<B_32_32_8>(a, st); break;
+        default: break;          // block1.conv (uint8 frames in): fp32-MFMA kernel with bf16 output, conv.hip
+    }
+}
+void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
+    switch (s) {
+        case CS_16_16_32: launch_bf_t<BD_16_16_32>(a, st); break;
+        case CS_16_32_32: launch_bf_t<BD_16_32_32>(a, st); break;
+        case CS_32_32_16: launch_bf_t<BD_32_32_16>(a, st); break;
+        case CS_32_32_8:  launch_bf_t<BD_32_32_8>(a, st); break;
+        default: break;
+    }
+}

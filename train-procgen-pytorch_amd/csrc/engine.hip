@@ -36,7 +36,7 @@ struct TensorDesc {
 };
 
 struct ConvLayer { ConvShape shape; int64_t w_off, b_off; int cin, cout, hw; };
-struct Block { float *C, *P0, *A1, *P1, *A2, *P2; uint8_t* PI; int cin, cout, hin; };
+struct Block { float *C, *P0, *A1, *P1, *A2, *P2; uint8_t* PI; int cin, cout, hin; };   // activation buffers hold fp32 or bf16 (ctx.bf)
 struct Linear { int64_t w_off, b_off; int in, out; };
 
 // ---- live kernel timing (bench.py roofline leg)
@@ -49,6 +49,7 @@ static const char* kProfNames[PC_COUNT] = {
 struct ProfPending { hipEvent_t a, b; int cls, phase; long long units; double bytes, flops; };
 struct Profiler {
     bool on = false;
+    bool all_phases = false;       // false: update phase only (the rollout's ~5.6k tiny launches per iteration are not bracketed)
     int phase = 0;
     std::vector<ProfPending> pend;
     std::vector<hipEvent_t> pool;
@@ -66,6 +67,8 @@ struct mi_ctx {
     hipStream_t stream;
     bool own_stream;
     int T, E, A, H, NB;
+    bool bf;              // IMPALA activations / activation gradients stored as bf16 (mi_config.precision == 1)
+    double es;            // bytes per activation element
     int64_t n_params;
     std::vector<TensorDesc> tensors;
     float *params, *grads, *adam_m, *adam_v;
@@ -220,6 +223,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     ARG(cfg->arch == MI_ARCH_IMPALA || cfg->arch == MI_ARCH_MLP, "arch");
     ARG(cfg->n_actions >= 1 && cfg->n_actions <= 16, "n_actions must be in [1,16]");
     ARG(cfg->n_steps >= 1 && cfg->n_envs >= 1 && cfg->max_batch >= 1, "n_steps/n_envs/max_batch");
+    ARG(cfg->precision == 0 || cfg->precision == 1, "precision must be 0 (fp32) or 1 (bf16 activations)");
     if (cfg->arch == MI_ARCH_MLP) ARG(cfg->obs_dim >= 1 && cfg->mlp_depth >= 2 && cfg->mlp_width >= 1 && cfg->out_dim >= 1, "mlp dims");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "no HIP device: the MI355X library has no CPU fallback");
@@ -229,6 +233,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->T = cfg->n_steps; c->E = cfg->n_envs; c->A = cfg->n_actions;
     c->H = (cfg->arch == MI_ARCH_IMPALA) ? 256 : cfg->out_dim;
     c->NB = cfg->max_batch < cfg->n_envs ? cfg->n_envs : cfg->max_batch;
+    c->bf = (cfg->arch == MI_ARCH_IMPALA) && cfg->precision == 1;
+    c->es = c->bf ? 2.0 : 4.0;
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     if (cfg->arch == MI_ARCH_IMPALA) build_impala_layout(c); else build_mlp_layout(c);
@@ -255,7 +261,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         }
         HIPC(dalloc(&c->GC, (size_t)NB * 64 * 64 * 16));
         for (int k = 0; k < 3; ++k) HIPC(dalloc(&c->GP[k], (size_t)NB * 32 * 32 * 16));
-        c->slab_floats = (size_t)512 * (32 * 9 * 32 + 32);
+        c->slab_floats = (size_t)1024 * (32 * 9 * 32 + 32);      // persistent grids never exceed 4 workgroups x 256 CUs
         HIPC(dalloc(&c->slabs, c->slab_floats));
         HIPC(dalloc(&c->fs_scratch, (size_t)64 * 2048));
     } else {
@@ -456,7 +462,8 @@ static void prof_harvest(mi_ctx* c) {
 struct ProfScope {
     mi_ctx* c; ProfPending p; bool live;
     // bytes / flops: ALGORITHMIC figures of this launch (layer-boundary model)
-    ProfScope(mi_ctx* c_, int cls, long long units, double bytes, double flops) : c(c_), live(c_->prof.on) {
+    ProfScope(mi_ctx* c_, int cls, long long units, double bytes, double flops)
+        : c(c_), live(c_->prof.on && (c_->prof.all_phases || c_->prof.phase == 1)) {
         if (!live) return;
         p.a = prof_event(c); p.b = prof_event(c); p.cls = cls; p.phase = c->prof.phase; p.units = units; p.bytes = bytes; p.flops = flops;
         hipEventRecord(p.a, c->stream);
@@ -468,7 +475,12 @@ struct ProfScope {
         if (c->prof.pend.size() >= 4096) prof_harvest(c);
     }
 };
-int mi_profile_enable(mi_ctx* c, int32_t enabled) { ARG(c, "null"); if (!enabled) prof_harvest(c); c->prof.on = enabled != 0; return 0; }
+int mi_profile_enable(mi_ctx* c, int32_t enabled) {
+    ARG(c, "null");
+    if (!enabled) prof_harvest(c);
+    c->prof.on = enabled != 0; c->prof.all_phases = enabled == 2;
+    return 0;
+}
 const char* mi_profile_class_name(int32_t id) { return (id >= 0 && id < PC_COUNT) ? kProfNames[id] : ""; }
 int mi_profile_read(mi_ctx* c, double* rows, int32_t max_rows, int32_t* n_rows, int32_t reset) {
     ARG(c && rows && n_rows, "null");
@@ -495,35 +507,37 @@ static void conv_fwd(mi_ctx* c, const ConvLayer& L, const void* in, const InputS
     ConvArgs a{};
     a.in = src ? src->base : in; a.idx = src ? src->idx : nullptr; a.in_base = src ? src->first : 0;
     a.w = c->params + L.w_off; a.bias = c->params + L.b_off; a.res = res; a.mask = nullptr; a.out = out;
-    a.lut = c->lut; a.n = n; a.relu_in = relu_in;
-    const double px = (double)n * L.hw * L.hw;
-    ProfScope ps(c, PC_CONV_FWD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : 4.0 * L.cin) + 4.0 * L.cout * (res ? 2 : 1)), px * 18.0 * L.cin * L.cout);
+    a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
+    const double px = (double)n * L.hw * L.hw, es = c->es;
+    ProfScope ps(c, PC_CONV_FWD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : es * L.cin) + es * L.cout * (res ? 2 : 1)), px * 18.0 * L.cin * L.cout);
     launch_conv_fwd(L.shape, a, c->stream);
 }
 static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const float* mask, const float* res, float* din, int n) {
     ConvArgs a{};
     a.in = dout; a.w = c->params + L.w_off; a.bias = nullptr; a.res = res; a.mask = mask; a.out = din;
-    a.lut = c->lut; a.n = n; a.relu_in = 0;
+    a.lut = c->lut; a.n = n; a.relu_in = 0; a.bf16 = c->bf;
     const double px = (double)n * L.hw * L.hw;
-    ProfScope ps(c, PC_CONV_DGRAD + (int)L.shape, n, px * 4.0 * (L.cout + L.cin * (1 + (mask ? 1 : 0) + (res ? 1 : 0))), px * 18.0 * L.cin * L.cout);
+    ProfScope ps(c, PC_CONV_DGRAD + (int)L.shape, n, px * c->es * (L.cout + L.cin * (1 + (mask ? 1 : 0) + (res ? 1 : 0))), px * 18.0 * L.cin * L.cout);
     launch_conv_dgrad(L.shape, a, c->stream);
 }
 static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const InputSrc* src, int relu_in, const float* dout, int n) {
     WgradArgs a{};
     a.in = src ? src->base : in; a.idx = src ? src->idx : nullptr; a.in_base = src ? src->first : 0;
-    a.dout = dout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in;
-    const int grid = wgrad_grid(L.shape, n);
+    a.dout = dout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
+    const int grid = wgrad_grid_for(L.shape, n, c->bf);
     if (grid < 1) return;
+    if ((size_t)grid * (size_t)(L.cout * 9 * L.cin + L.cout) > c->slab_floats) { fprintf(stderr, "mi355ppo: wgrad slab workspace too small\n"); abort(); }
     const double px = (double)n * L.hw * L.hw;
-    { ProfScope ps(c, PC_CONV_WGRAD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : 4.0 * L.cin) + 4.0 * L.cout), px * 18.0 * L.cin * L.cout);
+    { ProfScope ps(c, PC_CONV_WGRAD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : c->es * L.cin) + c->es * L.cout), px * 18.0 * L.cin * L.cout);
       launch_conv_wgrad(L.shape, a, c->stream); }
     const int wlen = L.cout * 9 * L.cin;
     ProfScope ps(c, PC_SLAB_REDUCE, n, 4.0 * grid * (wlen + L.cout), 0.0);
     launch_reduce_slabs(c->slabs, grid, wlen + L.cout, c->grads + L.w_off, wlen, c->grads + L.b_off, L.cout, c->stream);
 }
 
-static void linear_fwd(mi_ctx* c, const float* X, int relu_x, const float* W, const float* b, float* Y, int n, int in, int out, int relu_out) {
+static void linear_fwd(mi_ctx* c, const float* X, int relu_x, const float* W, const float* b, float* Y, int n, int in, int out, int relu_out, int x_bf16 = 0) {
     GemmArgs g{};
+    g.a_bf16 = x_bf16;
     g.A = X; g.B = W; g.C = Y; g.M = n; g.N = out; g.K = in;
     g.sam = in; g.sak = 1; g.sbk = 1; g.sbn = in; g.ldc = out;
     g.bias = b; g.relu_a = relu_x; g.relu_out = relu_out;
@@ -531,16 +545,18 @@ static void linear_fwd(mi_ctx* c, const float* X, int relu_x, const float* W, co
     launch_gemm(g, c->stream);
 }
 // dX = dY W  (* mask > 0)
-static void linear_dgrad(mi_ctx* c, const float* dY, const float* W, const float* mask, float* dX, int n, int in, int out) {
+static void linear_dgrad(mi_ctx* c, const float* dY, const float* W, const float* mask, float* dX, int n, int in, int out, int x_bf16 = 0) {
     GemmArgs g{};
+    g.mask_bf16 = x_bf16; g.c_bf16 = x_bf16;          // mask source and dX are activation-typed
     g.A = dY; g.B = W; g.C = dX; g.M = n; g.N = in; g.K = out;
     g.sam = out; g.sak = 1; g.sbk = in; g.sbn = 1; g.ldc = in; g.mask = mask;
     ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * out + (double)in * out + (double)n * in * (mask ? 2 : 1)), 2.0 * n * in * out);
     launch_gemm(g, c->stream);
 }
 // gW += dY^T relu?(X) ; gb += colsum(dY)
-static void linear_wgrad(mi_ctx* c, const float* dY, const float* X, int relu_x, float* gW, float* gb, int n, int in, int out) {
+static void linear_wgrad(mi_ctx* c, const float* dY, const float* X, int relu_x, float* gW, float* gb, int n, int in, int out, int x_bf16 = 0) {
     GemmArgs g{};
+    g.b_bf16 = x_bf16;
     g.A = dY; g.B = X; g.C = gW; g.M = out; g.N = in; g.K = n;
     g.sam = 1; g.sak = out; g.sbk = in; g.sbn = 1; g.ldc = in; g.relu_b = relu_x; g.accumulate = 1;
     ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * out + (double)n * in + (double)in * out), 2.0 * n * in * out);
@@ -568,14 +584,15 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
             const ConvLayer* L = &c->convs[b * 5];
             if (b == 0) conv_fwd(c, L[0], nullptr, &src, 0, nullptr, k.C, n);
             else conv_fwd(c, L[0], prev, nullptr, 0, nullptr, k.C, n);
-            { ProfScope ps(c, PC_POOL_FWD, n, (double)n * k.hin * k.hin * k.cout * (4.0 + 1.25), 0.0); launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); }
+            { ProfScope ps(c, PC_POOL_FWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
+              if (c->bf) launch_maxpool_fwd_bf16(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); else launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); }
             conv_fwd(c, L[1], k.P0, nullptr, 1, nullptr, k.A1, n);
             conv_fwd(c, L[2], k.A1, nullptr, 1, k.P0, k.P1, n);
             conv_fwd(c, L[3], k.P1, nullptr, 1, nullptr, k.A2, n);
             conv_fwd(c, L[4], k.A2, nullptr, 1, k.P1, k.P2, n);
             prev = k.P2;
         }
-        linear_fwd(c, c->blk[2].P2, 1, c->params + c->fc.w_off, c->params + c->fc.b_off, c->feat, n, 2048, c->H, 1);
+        linear_fwd(c, c->blk[2].P2, 1, c->params + c->fc.w_off, c->params + c->fc.b_off, c->feat, n, 2048, c->H, 1, c->bf);
     } else {
         launch_gather_rows((const float*)src.base, src.idx, src.first, c->mlp_act[0], n, c->cfg.obs_dim, c->stream);
         const size_t L = c->mlp.size();
@@ -605,11 +622,11 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         }
         return;
     }
-    linear_wgrad(c, c->dfeat, c->blk[2].P2, 1, c->grads + c->fc.w_off, c->grads + c->fc.b_off, n, 2048, c->H);
+    linear_wgrad(c, c->dfeat, c->blk[2].P2, 1, c->grads + c->fc.w_off, c->grads + c->fc.b_off, n, 2048, c->H, c->bf);
     float* Gout = c->GP[0];
     float* Ga = c->GP[1];
     float* Gb = c->GP[2];
-    linear_dgrad(c, c->dfeat, c->params + c->fc.w_off, c->blk[2].P2, Gout, n, 2048, c->H);
+    linear_dgrad(c, c->dfeat, c->params + c->fc.w_off, c->blk[2].P2, Gout, n, 2048, c->H, c->bf);
     for (int b = 2; b >= 0; --b) {
         Block& k = c->blk[b];
         const ConvLayer* L = &c->convs[b * 5];
@@ -624,7 +641,8 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         conv_wgrad(c, L[1], k.P0, nullptr, 1, Ga, n);
         conv_dgrad(c, L[1], Ga, k.P0, Gb, Gout, n);
         // max pool, then the block's first conv
-        { ProfScope ps(c, PC_POOL_BWD, n, (double)n * k.hin * k.hin * k.cout * (4.0 + 1.25), 0.0); launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); }
+        { ProfScope ps(c, PC_POOL_BWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
+          if (c->bf) launch_maxpool_bwd_bf16(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); else launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); }
         if (b == 0) conv_wgrad(c, L[0], nullptr, &src, 0, c->GC, n);
         else {
             conv_wgrad(c, L[0], c->blk[b - 1].P2, nullptr, 0, c->GC, n);
@@ -804,7 +822,7 @@ int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, con
     c->prof.phase = 1;
     net_forward(c, src, n);
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
-    if (impala) launch_fs_metric(c->blk[2].P2, n, 2048, c->fs_scratch, c->fs_val, c->stream);
+    if (impala) launch_fs_metric(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_val, c->stream);
     LossArgs a{};
     a.hout = c->hout; a.idx = c->d_idx; a.act = c->act; a.old_logp = c->logp; a.old_value = c->value; a.ret = c->ret; a.adv = c->adv;
     a.dY = c->dY; a.partial = c->loss_partial; a.stats = c->loss_stats; a.n = n; a.A = c->A;
@@ -890,6 +908,28 @@ static int shape_of(int cin, int cout, int hw, ConvShape* s) {
     return fail(-1, "unsupported conv shape");
 }
 
+// host-side activation conversion for the op-level entry points of a bf16 context (round to nearest even)
+static std::vector<uint16_t> host_to_bf16(const float* x, size_t n) {
+    std::vector<uint16_t> o(n);
+    for (size_t k = 0; k < n; ++k) { uint32_t u; memcpy(&u, x + k, 4); o[k] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); }
+    return o;
+}
+static void host_from_bf16(const uint16_t* h, float* x, size_t n) {
+    for (size_t k = 0; k < n; ++k) { const uint32_t u = ((uint32_t)h[k]) << 16; memcpy(x + k, &u, 4); }
+}
+// upload an activation tensor in the context's storage type
+static int upload_act(mi_ctx* c, const float* host, size_t n, void** dev) {
+    HIPC(hipMalloc(dev, n * 4 + 256));
+    if (c->bf) { auto h = host_to_bf16(host, n); HIPC(hipMemcpy(*dev, h.data(), n * 2, hipMemcpyHostToDevice)); }
+    else HIPC(hipMemcpy(*dev, host, n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+static int download_act(mi_ctx* c, const void* dev, float* host, size_t n) {
+    if (c->bf) { std::vector<uint16_t> h(n); HIPC(hipMemcpy(h.data(), dev, n * 2, hipMemcpyDeviceToHost)); host_from_bf16(h.data(), host, n); }
+    else HIPC(hipMemcpy(host, dev, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw, int32_t n, const void* in, int32_t in_is_u8,
                   int32_t relu_in, const float* w_ref, const float* bias, const float* res, const float* mask, const float* dout,
                   float* out, float* dbias_out) {
@@ -901,34 +941,34 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
     TensorDesc td{"w", 0, 0, (int64_t)cout * cin * 9, K_CONVW, cout, cin};
     std::vector<float> wdev(td.n);
     to_device_layout(td, w_ref, wdev.data());
-    float *dw = nullptr, *db = nullptr, *din = nullptr, *dres = nullptr, *dmask = nullptr, *ddout = nullptr, *dout_buf = nullptr;
+    float *dw = nullptr, *db = nullptr;
+    void *din = nullptr, *dres = nullptr, *dmask = nullptr, *ddout = nullptr, *dout_buf = nullptr;
     HIPC(dalloc(&dw, td.n)); HIPC(hipMemcpy(dw, wdev.data(), td.n * 4, hipMemcpyHostToDevice));
     if (bias) { HIPC(dalloc(&db, cout)); HIPC(hipMemcpy(db, bias, cout * 4, hipMemcpyHostToDevice)); }
-    const int in_ch = (mode == 1) ? cout : cin, out_ch = (mode == 1) ? cin : cout;
+    const int out_ch = (mode == 1) ? cin : cout;
     if (mode != 1) {
-        const size_t ib = in_is_u8 ? px * 3 : px * cin * 4;
-        HIPC(hipMalloc((void**)&din, ib + 256)); HIPC(hipMemcpy(din, in, ib, hipMemcpyHostToDevice));
+        if (in_is_u8) { HIPC(hipMalloc(&din, px * 3 + 256)); HIPC(hipMemcpy(din, in, px * 3, hipMemcpyHostToDevice)); }
+        else if (int r = upload_act(c, (const float*)in, px * cin, &din)) return r;
     }
-    if (mode >= 1) { ARG(dout, "dout"); HIPC(dalloc(&ddout, px * cout)); HIPC(hipMemcpy(ddout, dout, px * cout * 4, hipMemcpyHostToDevice)); }
-    if (res) { HIPC(dalloc(&dres, px * out_ch)); HIPC(hipMemcpy(dres, res, px * out_ch * 4, hipMemcpyHostToDevice)); }
-    if (mask) { HIPC(dalloc(&dmask, px * out_ch)); HIPC(hipMemcpy(dmask, mask, px * out_ch * 4, hipMemcpyHostToDevice)); }
-    (void)in_ch;
+    if (mode >= 1) { ARG(dout, "dout"); if (int r = upload_act(c, dout, px * cout, &ddout)) return r; }
+    if (res) { if (int r = upload_act(c, res, px * out_ch, &dres)) return r; }
+    if (mask) { if (int r = upload_act(c, mask, px * out_ch, &dmask)) return r; }
     if (mode <= 1) {
-        HIPC(dalloc(&dout_buf, px * out_ch));
+        HIPC(hipMalloc(&dout_buf, px * out_ch * 4 + 256));
         ConvArgs a{};
-        a.in = (mode == 0) ? (const void*)din : (const void*)ddout; a.idx = nullptr; a.in_base = 0; a.w = dw; a.bias = (mode == 0) ? db : nullptr;
-        a.res = dres; a.mask = dmask; a.out = dout_buf; a.lut = c->lut; a.n = n; a.relu_in = (mode == 0) ? relu_in : 0;
+        a.in = (mode == 0) ? din : ddout; a.idx = nullptr; a.in_base = 0; a.w = dw; a.bias = (mode == 0) ? db : nullptr;
+        a.res = dres; a.mask = dmask; a.out = dout_buf; a.lut = c->lut; a.n = n; a.relu_in = (mode == 0) ? relu_in : 0; a.bf16 = c->bf;
         if (mode == 0) launch_conv_fwd(s, a, c->stream); else launch_conv_dgrad(s, a, c->stream);
         HIPC(hipGetLastError());
         HIPC(hipStreamSynchronize(c->stream));
-        HIPC(hipMemcpy(out, dout_buf, px * out_ch * 4, hipMemcpyDeviceToHost));
+        if (int r = download_act(c, dout_buf, out, px * out_ch)) return r;
     } else {
         ARG(c->slabs, "wgrad needs an IMPALA context");
         float* g = nullptr;
         HIPC(dalloc(&g, td.n + cout));
         WgradArgs a{};
-        a.in = din; a.idx = nullptr; a.in_base = 0; a.dout = ddout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in;
-        const int grid = wgrad_grid(s, n);
+        a.in = din; a.idx = nullptr; a.in_base = 0; a.dout = ddout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
+        const int grid = wgrad_grid_for(s, n, c->bf);
         launch_conv_wgrad(s, a, c->stream);
         launch_reduce_slabs(c->slabs, grid, (int)td.n + cout, g, (int)td.n, g + td.n, cout, c->stream);
         HIPC(hipGetLastError());
@@ -939,26 +979,26 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
         if (dbias_out) memcpy(dbias_out, hg.data() + td.n, cout * 4);
         hipFree(g);
     }
-    float* fr[] = {dw, db, din, dres, dmask, ddout, dout_buf};
-    for (float* p : fr) if (p) hipFree(p);
+    void* fr[] = {dw, db, din, dres, dmask, ddout, dout_buf};
+    for (void* p : fr) if (p) hipFree(p);
     return 0;
 }
 
 int mi_op_maxpool(mi_ctx* c, int32_t mode, int32_t n, int32_t hw, int32_t ch, const float* in, const float* dout, float* out) {
     ARG(c && in && out, "null");
     const size_t X = (size_t)n * hw * hw * ch, p = X / 4;
-    float *din = nullptr, *dp = nullptr, *dd = nullptr, *dg = nullptr; uint8_t* di = nullptr;
-    HIPC(dalloc(&din, X)); HIPC(dalloc(&dp, p)); HIPC(dalloc(&di, p));
-    HIPC(hipMemcpy(din, in, X * 4, hipMemcpyHostToDevice));
-    launch_maxpool_fwd(din, dp, di, n, hw, ch, c->stream);
-    if (mode == 0) { HIPC(hipStreamSynchronize(c->stream)); HIPC(hipMemcpy(out, dp, p * 4, hipMemcpyDeviceToHost)); }
+    void *din = nullptr, *dp = nullptr, *dd = nullptr, *dg = nullptr; uint8_t* di = nullptr;
+    if (int r = upload_act(c, in, X, &din)) return r;
+    HIPC(hipMalloc(&dp, p * 4 + 256)); HIPC(dalloc(&di, p));
+    if (c->bf) launch_maxpool_fwd_bf16(din, dp, di, n, hw, ch, c->stream); else launch_maxpool_fwd((const float*)din, (float*)dp, di, n, hw, ch, c->stream);
+    if (mode == 0) { HIPC(hipStreamSynchronize(c->stream)); if (int r = download_act(c, dp, out, p)) return r; }
     else {
         ARG(dout, "dout");
-        HIPC(dalloc(&dd, p)); HIPC(dalloc(&dg, X));
-        HIPC(hipMemcpy(dd, dout, p * 4, hipMemcpyHostToDevice));
-        launch_maxpool_bwd(dd, di, dg, n, hw, ch, c->stream);
+        if (int r = upload_act(c, dout, p, &dd)) return r;
+        HIPC(hipMalloc(&dg, X * 4 + 256));
+        if (c->bf) launch_maxpool_bwd_bf16(dd, di, dg, n, hw, ch, c->stream); else launch_maxpool_bwd((const float*)dd, di, (float*)dg, n, hw, ch, c->stream);
         HIPC(hipStreamSynchronize(c->stream));
-        HIPC(hipMemcpy(out, dg, X * 4, hipMemcpyDeviceToHost));
+        if (int r = download_act(c, dg, out, X)) return r;
     }
     HIPC(hipGetLastError());
     hipFree(din); hipFree(dp); hipFree(di); if (dd) hipFree(dd); if (dg) hipFree(dg);

@@ -34,6 +34,7 @@ __device__ __forceinline__ T block_sum256(T v, T* sbuf) {
 // quarter q owns k = 4q..4q+3 of the K tile (one ds_read_b128 per operand per 4 MFMAs).
 // Used for: embedder.fc, the policy/value heads and the MLP embedder (forward, dgrad, wgrad) --
 // nn.Linear in common/model.py:176,199 / :966-971 and common/policy.py:39-40,75,80.
+__device__ __forceinline__ unsigned short f2bf_g(float x) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int k_chunk, float* ws) {
     __shared__ __attribute__((aligned(16))) float As[64 * 20];
     __shared__ __attribute__((aligned(16))) float Bs[64 * 20];
@@ -55,12 +56,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int k_chunk, floa
             int m, k;
             if (a_kc) { m = l >> 4; k = l & 15; } else { m = l & 63; k = l >> 6; }
             float v = 0.f;
-            if (m0 + m < g.M && k0 + k < kend) { v = g.A[(long long)(m0 + m) * g.sam + (long long)(k0 + k) * g.sak]; if (g.relu_a) v = fmaxf(v, 0.f); }
+            if (m0 + m < g.M && k0 + k < kend) {
+                const long long o = (long long)(m0 + m) * g.sam + (long long)(k0 + k) * g.sak;
+                v = g.a_bf16 ? __uint_as_float(((unsigned)((const unsigned short*)g.A)[o]) << 16) : g.A[o];
+                if (g.relu_a) v = fmaxf(v, 0.f);
+            }
             As[m * 20 + k] = v;
             int n;
             if (b_kc) { n = l >> 4; k = l & 15; } else { n = l & 63; k = l >> 6; }
             v = 0.f;
-            if (n0 + n < g.N && k0 + k < kend) { v = g.B[(long long)(k0 + k) * g.sbk + (long long)(n0 + n) * g.sbn]; if (g.relu_b) v = fmaxf(v, 0.f); }
+            if (n0 + n < g.N && k0 + k < kend) {
+                const long long o = (long long)(k0 + k) * g.sbk + (long long)(n0 + n) * g.sbn;
+                v = g.b_bf16 ? __uint_as_float(((unsigned)((const unsigned short*)g.B)[o]) << 16) : g.B[o];
+                if (g.relu_b) v = fmaxf(v, 0.f);
+            }
             Bs[n * 20 + k] = v;
         }
         __syncthreads();
@@ -89,7 +98,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int k_chunk, floa
                     const long long o = (long long)m * g.ldc + n;
                     if (g.bias) v += g.bias[n];
                     if (g.relu_out) v = fmaxf(v, 0.f);
-                    if (g.mask) v = g.mask[o] > 0.f ? v : 0.f;
+                    if (g.mask) {
+                        const float mv = g.mask_bf16 ? __uint_as_float(((unsigned)((const unsigned short*)g.mask)[o]) << 16) : g.mask[o];
+                        v = mv > 0.f ? v : 0.f;
+                    }
+                    if (g.c_bf16) { ((unsigned short*)g.C)[o] = f2bf_g(v); continue; }
                     if (g.accumulate) v += g.C[o];
                     g.C[o] = v;
                 }
@@ -105,7 +118,11 @@ __global__ void gemm_splitk_reduce(const float* ws, int split, GemmArgs g) {
     const long long o = (e / g.N) * g.ldc + n;
     if (g.bias) v += g.bias[n];
     if (g.relu_out) v = fmaxf(v, 0.f);
-    if (g.mask) v = g.mask[o] > 0.f ? v : 0.f;
+    if (g.mask) {
+        const float mv = g.mask_bf16 ? __uint_as_float(((unsigned)((const unsigned short*)g.mask)[o]) << 16) : g.mask[o];
+        v = mv > 0.f ? v : 0.f;
+    }
+    if (g.c_bf16) { ((unsigned short*)g.C)[o] = f2bf_g(v); return; }
     if (g.accumulate) v += g.C[o];
     g.C[o] = v;
 }
@@ -193,6 +210,104 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         }
     }
     *(f32x4*)(din + (size_t)e * 4) = s;
+}
+
+__device__ __forceinline__ float bfw_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfw_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned short f2bf_m(float x) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
+
+// bf16 storage: 8 channels (16 bytes) per thread; comparisons on the exact bf16 values
+template <int HW, int C>
+__global__ __launch_bounds__(256) void maxpool_fwd_bf16_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+                                                               uint8_t* __restrict__ arg, int n) {
+    constexpr int HO = HW / 2, C8 = C / 8;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    const unsigned tot = (unsigned)n * HO * HO * C8;
+    if (e >= tot) return;
+    const unsigned c8 = e % C8, ox = (e / C8) % HO, oy = (e / (C8 * HO)) % HO, img = e / (C8 * HO * HO);
+    float best[8];
+    unsigned bw[4] = {0, 0, 0, 0};       // winning bf16 bits, packed
+    unsigned bi[8];
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int y = 2 * (int)oy - 1 + ky, x = 2 * (int)ox - 1 + kx;
+            if (y < 0 || y >= HW || x < 0 || x >= HW) continue;
+            const uint4 u = *(const uint4*)(in + (((size_t)img * HW + y) * HW + x) * C + c8 * 8);
+            const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = (k & 1) ? bfw_hi(w[k >> 1]) : bfw_lo(w[k >> 1]);
+                if (first || v > best[k] || v != v) {
+                    best[k] = v; bi[k] = ky * 3 + kx;
+                    const unsigned bits = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu);
+                    bw[k >> 1] = (k & 1) ? ((bw[k >> 1] & 0x0000ffffu) | (bits << 16)) : ((bw[k >> 1] & 0xffff0000u) | bits);
+                }
+            }
+            first = false;
+        }
+    *(uint4*)(out + (size_t)e * 8) = (uint4){bw[0], bw[1], bw[2], bw[3]};
+    *(uint2*)(arg + (size_t)e * 8) = (uint2){bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24)};
+}
+
+template <int HW, int C>
+__global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const unsigned short* __restrict__ dout, const uint8_t* __restrict__ arg,
+                                                               unsigned short* __restrict__ din, int n) {
+    constexpr int HO = HW / 2, C8 = C / 8;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    const unsigned tot = (unsigned)n * HW * HW * C8;
+    if (e >= tot) return;
+    const unsigned c8 = e % C8, x = (e / C8) % HW, y = (e / (C8 * HW)) % HW, img = e / (C8 * HW * HW);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (unsigned oy = y / 2; oy <= (y + 1) / 2; ++oy) {
+        if (oy >= HO) continue;
+        for (unsigned ox = x / 2; ox <= (x + 1) / 2; ++ox) {
+            if (ox >= HO) continue;
+            const size_t o = ((((size_t)img * HO + oy) * HO + ox) * C8 + c8) * 8;
+            const unsigned pos = (y - (2 * oy - 1)) * 3 + (x - (2 * ox - 1));
+            const uint2 a = *(const uint2*)(arg + o);
+            const uint4 d = *(const uint4*)(dout + o);
+            const unsigned w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned ak = ((k < 4 ? a.x : a.y) >> (8 * (k & 3))) & 0xffu;
+                if (ak == pos) s[k] += (k & 1) ? bfw_hi(w[k >> 1]) : bfw_lo(w[k >> 1]);
+            }
+        }
+    }
+    uint4 r;
+    r.x = f2bf_m(s[0]) | ((unsigned)f2bf_m(s[1]) << 16); r.y = f2bf_m(s[2]) | ((unsigned)f2bf_m(s[3]) << 16);
+    r.z = f2bf_m(s[4]) | ((unsigned)f2bf_m(s[5]) << 16); r.w = f2bf_m(s[6]) | ((unsigned)f2bf_m(s[7]) << 16);
+    *(uint4*)(din + (size_t)e * 8) = r;
+}
+
+template <int HW, int C>
+static void pool_fwd_bf_t(const void* in, void* out, uint8_t* arg, int n, hipStream_t st) {
+    const unsigned tot = (unsigned)n * (HW / 2) * (HW / 2) * (C / 8);
+    hipLaunchKernelGGL((maxpool_fwd_bf16_kernel<HW, C>), dim3((tot + 255) / 256), dim3(256), 0, st, (const unsigned short*)in, (unsigned short*)out, arg, n);
+}
+template <int HW, int C>
+static void pool_bwd_bf_t(const void* dout, const uint8_t* arg, void* din, int n, hipStream_t st) {
+    const unsigned tot = (unsigned)n * HW * HW * (C / 8);
+    hipLaunchKernelGGL((maxpool_bwd_bf16_kernel<HW, C>), dim3((tot + 255) / 256), dim3(256), 0, st, (const unsigned short*)dout, arg, (unsigned short*)din, n);
+}
+void launch_maxpool_fwd_bf16(const void* in, void* out, uint8_t* arg, int n, int hw, int c, hipStream_t st) {
+    if (n <= 0) return;
+    if (hw == 64 && c == 16) pool_fwd_bf_t<64, 16>(in, out, arg, n, st);
+    else if (hw == 32 && c == 32) pool_fwd_bf_t<32, 32>(in, out, arg, n, st);
+    else if (hw == 16 && c == 32) pool_fwd_bf_t<16, 32>(in, out, arg, n, st);
+    else abort();
+}
+void launch_maxpool_bwd_bf16(const void* dout, const uint8_t* arg, void* din, int n, int hw, int c, hipStream_t st) {
+    if (n <= 0) return;
+    if (hw == 64 && c == 16) pool_bwd_bf_t<64, 16>(dout, arg, din, n, st);
+    else if (hw == 32 && c == 32) pool_bwd_bf_t<32, 32>(dout, arg, din, n, st);
+    else if (hw == 16 && c == 32) pool_bwd_bf_t<16, 32>(dout, arg, din, n, st);
+    else abort();
 }
 
 template <int HW, int C>
@@ -419,11 +534,17 @@ void launch_loss_bwd(const LossArgs& a, hipStream_t st) {
 
 // feature-sparsity metric (common/model.py:207): mean_j max_b tanh(|100*relu(h_bj)|)
 // = mean_j tanh(100 * max_b relu(h_bj)) (tanh monotone).  flat_pre is block3's output BEFORE the ReLU.
-__global__ void colmax_partial_kernel(const float* x, int n, int d, float* part) {
+__global__ void colmax_partial_kernel(const void* x, int bf16, int n, int d, float* part) {
     const int j = blockIdx.x * 64 + (threadIdx.x & 63), rg = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int groups = gridDim.y * 4;
     float m = 0.f;
-    if (j < d) { for (int b = rg; b < n; b += groups) m = fmaxf(m, x[(long long)b * d + j]); part[(long long)rg * d + j] = m; }
+    if (j < d) {
+        for (int b = rg; b < n; b += groups) {
+            const long long o = (long long)b * d + j;
+            m = fmaxf(m, bf16 ? __uint_as_float(((unsigned)((const unsigned short*)x)[o]) << 16) : ((const float*)x)[o]);
+        }
+        part[(long long)rg * d + j] = m;
+    }
 }
 __global__ __launch_bounds__(256) void fs_finalize_kernel(const float* part, int groups, int d, float* fs_out) {
     __shared__ double sb[4];
@@ -436,9 +557,9 @@ __global__ __launch_bounds__(256) void fs_finalize_kernel(const float* part, int
     const double tot = block_sum256(s, sb);
     if (threadIdx.x == 0) fs_out[0] = (float)(tot / d);
 }
-void launch_fs_metric(const float* flat_pre, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st) {
+void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(colmax_partial_kernel, dim3((d + 63) / 64, 16), dim3(256), 0, st, flat_pre, n, d, colmax_scratch);
+    hipLaunchKernelGGL(colmax_partial_kernel, dim3((d + 63) / 64, 16), dim3(256), 0, st, flat_pre, bf16, n, d, colmax_scratch);
     hipLaunchKernelGGL(fs_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)colmax_scratch, 64, d, fs_out);
 }
 

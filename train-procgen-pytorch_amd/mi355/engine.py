@@ -24,7 +24,8 @@ class EngineError(RuntimeError):
 class _Config(C.Structure):
     _fields_ = [("arch", C.c_int32), ("n_steps", C.c_int32), ("n_envs", C.c_int32), ("n_actions", C.c_int32),
                 ("obs_dim", C.c_int32), ("mlp_depth", C.c_int32), ("mlp_width", C.c_int32), ("out_dim", C.c_int32),
-                ("max_batch", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32 * 6), ("stream", C.c_void_p)]
+                ("max_batch", C.c_int32), ("device", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32 * 5),
+                ("stream", C.c_void_p)]
 
 
 class _HParams(C.Structure):
@@ -76,12 +77,13 @@ class Engine:
     """One device context (one GPU).  Methods mirror the C entry points one to one."""
 
     def __init__(self, arch, n_steps, n_envs, n_actions, max_batch, obs_dim=0, mlp_depth=0, mlp_width=0, out_dim=256,
-                 device=0, stream=None):
+                 device=0, stream=None, precision="fp32"):
         self.lib = load_library()
         self.arch = ARCH_IMPALA if arch in ("impala", ARCH_IMPALA) else ARCH_MLP
         cfg = _Config(arch=self.arch, n_steps=n_steps, n_envs=n_envs, n_actions=n_actions, obs_dim=obs_dim,
                       mlp_depth=mlp_depth, mlp_width=mlp_width, out_dim=out_dim, max_batch=max_batch, device=device,
-                      stream=stream)
+                      precision={"fp32": 0, "bf16": 1}[precision], stream=stream)
+        self.precision = precision
         self.T, self.E, self.A, self.max_batch = n_steps, n_envs, n_actions, max(max_batch, n_envs)
         self.H = 256 if self.arch == ARCH_IMPALA else out_dim
         self.obs_dim = obs_dim
@@ -284,8 +286,9 @@ class Engine:
         return p.value, n.value
 
     # ------------------------------------------------------------------ live kernel timing
-    def profile_enable(self, on=True):
-        self._chk(self.lib.mi_profile_enable(self._ctx, C.c_int32(int(on))))
+    def profile_enable(self, mode=1):
+        """0 off, 1 update-phase kernels only, 2 rollout + update."""
+        self._chk(self.lib.mi_profile_enable(self._ctx, C.c_int32(int(mode))))
 
     def profile_read(self, reset=True):
         rows = np.zeros((64, 7), np.float64)
