@@ -146,12 +146,12 @@ def main():
             h[...] = rng.integers(0, 256, size=h.shape, dtype=np.uint8)
 
     def iteration(it):
-        for t in range(T):
+        for t in range(T + 1):                          # T policy steps + the bootstrap-value step
             if host_frames is not None:
                 eng.put_obs(t, host_frames[t & 3])
-            eng.policy_step(t, seed=it)                 # returns act/logp/value to the host (env.step needs act)
-            eng.put_step(t, rew[t], done[t])
-        eng.policy_step(T, seed=it)
+            # act/logp/value come back to the host every step (env.step needs act); the previous step's
+            # reward / done (what env.step returned) go up with the same call
+            eng.rollout_step(t, rew[t - 1] if t else None, done[t - 1] if t else None, seed=it)
         storage.compute_estimates(hp["gamma"], hp["lmbda"], hp["use_gae"], hp["normalize_adv"], agent.coll)
         return agent.optimize()
 

@@ -83,6 +83,13 @@ int mi_write_field(mi_ctx* ctx, int32_t field, const float* in, int64_t n);
 int mi_policy_step(mi_ctx* ctx, int32_t t, uint64_t seed, const float* u,
                    int64_t* act_out, float* logp_out, float* value_out);
 
+/* ---- one call per rollout step for the agent's own loop (agents/ppo.py:228-231 fused): stores the PREVIOUS step's
+ *      reward / done (t >= 1; what Storage.store(t-1) receives after env.step), runs the policy step on slot t
+ *      (forward, GRU if set -- its done mask is done_prev --, fused heads + sample) and returns act / logp / value
+ *      through ONE packed read-back.  rew_prev / done_prev may be NULL (t == 0). */
+int mi_rollout_step(mi_ctx* ctx, int32_t t, const float* rew_prev, const float* done_prev, uint64_t seed, const float* u,
+                    int64_t* act_out, float* logp_out, float* value_out);
+
 /* ---- PPO.predict(obs, hidden, done) on caller data (agents/ppo.py:72-81) when the caller has not said which
  *      storage slot the observation belongs to: obs (E frames / rows) is staged on the device, forward + sample
  *      run on it, and mi_commit_staged(t) later moves the staged observation and policy outputs into ring slot t

@@ -335,8 +335,18 @@ def test_policy_step_sampling():
     assert np.array_equal(eng.read_field(M.F_ACT)[1], act.astype(np.float32))
     np.testing.assert_array_equal(eng.read_field(M.F_LOGP)[1], logp)
     np.testing.assert_array_equal(eng.read_field(M.F_VALUE)[1], val)
+    # the agent's fused per-step call (packed copies, heads + sample in one kernel) == policy_step + put_step
+    rew, dn = rng.standard_normal(E).astype(np.float32), (rng.random(E) < 0.5).astype(np.float32)
+    act2, logp2, val2 = eng.rollout_step(1, rew, dn, seed=0, u=u)
+    assert np.array_equal(act2[~edge], act[~edge])
+    np.testing.assert_allclose(logp2[~edge], logp[~edge], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(val2, val, rtol=0, atol=1e-6)
+    assert np.array_equal(eng.read_field(M.F_REW)[0], rew) and np.array_equal(eng.read_field(M.F_DONE)[0], dn)
+    assert np.array_equal(eng.read_field(M.F_ACT)[1], act2.astype(np.float32))
+    a1r, _, _ = eng.rollout_step(2, seed=7)
     # Philox path: deterministic in (seed, t), different across seeds, log-probs consistent
     a1, l1, _ = eng.policy_step(2, seed=7)
+    assert np.array_equal(a1, a1r)                         # same Philox stream in both entry points
     a2, l2, _ = eng.policy_step(2, seed=7)
     a3, _, _ = eng.policy_step(2, seed=8)
     assert np.array_equal(a1, a2) and np.array_equal(l1, l2) and not np.array_equal(a1, a3)

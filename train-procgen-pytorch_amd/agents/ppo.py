@@ -106,7 +106,7 @@ class PPO(BaseAgent):
         rec = self.policy.is_recurrent()
         if rec:
             engine.rec_state(hidden_state, done)
-        act, logp, value = engine.policy_step(t, seed=self.seed * 1000003 + self._iter)
+        act, logp, value = engine.rollout_step(t, seed=self.seed * 1000003 + self._iter)
         storage.note_predicted(t, obs, act, logp, value)
         return act, logp, value, (engine.get_hidden() if rec else hidden_state)
 

@@ -115,6 +115,10 @@ void launch_advnorm_apply(float* adv, int n, const double* stats3, hipStream_t s
 void launch_sample(const float* hout, int n, int A, const float* u, unsigned long long seed, unsigned long long ctr,
                    int32_t* act, float* logp, float* value, hipStream_t st);
 
+void launch_heads_sample(const float* feat, const float* Wh, const float* bh, int n, int H, int A, const float* u,
+                         unsigned long long seed, unsigned long long ctr, int32_t* act, float* logp, float* value, float* pack,
+                         float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st);
+void sumsq_set_workspace(double* ws);
 void launch_sumsq(const float* g, long long n, double* out, hipStream_t st);          // out[0] = sum g^2 (deterministic)
 void launch_adam(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr,
                  float beta1, float beta2, float eps, float step_size_scale, float bc2_sqrt, float* gnorm_out,

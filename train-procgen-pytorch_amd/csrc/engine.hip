@@ -95,6 +95,7 @@ struct mi_ctx {
     float *loss_partial, *loss_stats, *loss_log; int log_count, log_cap;
     double* sumsq; float* gnorm;
     float* d_u; float* d_lp;
+    float *d_pack, *h_pack, *h_rd, *d_rd;     // packed rollout read-back {act,logp,value} x E ; packed {rew,done} upload
     int32_t* s_act; float *s_logp, *s_val; bool staged_valid;
     // recurrent rollout (GRU cell, never trained)
     bool gru_on; float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *h_state, *h_masked, *gru_gi, *gru_gh, *d_done;
@@ -294,8 +295,10 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(dalloc(&c->loss_stats, 64));
     c->log_cap = 4096; c->log_count = 0;
     HIPC(dalloc(&c->loss_log, (size_t)c->log_cap * 8));
-    HIPC(dalloc(&c->sumsq, 2)); HIPC(dalloc(&c->gnorm, 2));
+    HIPC(dalloc(&c->sumsq, 2 + 128)); HIPC(dalloc(&c->gnorm, 2)); sumsq_set_workspace(c->sumsq + 2);
     HIPC(dalloc(&c->d_u, (size_t)E));
+    HIPC(dalloc(&c->d_pack, (size_t)3 * E)); HIPC(dalloc(&c->d_rd, (size_t)2 * E));
+    HIPC(hipHostMalloc((void**)&c->h_pack, (size_t)3 * E * 4)); HIPC(hipHostMalloc((void**)&c->h_rd, (size_t)2 * E * 4));
     HIPC(dalloc(&c->s_act, (size_t)E)); HIPC(dalloc(&c->s_logp, (size_t)E)); HIPC(dalloc(&c->s_val, (size_t)E)); c->staged_valid = false;
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) {
         HIPC(hipHostMalloc((void**)&c->h_idx_ring[k], (size_t)NB * sizeof(int32_t)));
@@ -329,11 +332,12 @@ int mi_destroy(mi_ctx* c) {
     if (c->frames) hipFree(c->frames);
     if (c->stage_frames) hipFree(c->stage_frames);
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
+    hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
     hipHostFree(c->h_f); hipHostFree(c->h_i);
-    gemm_set_workspace(nullptr, 0);
+    gemm_set_workspace(nullptr, 0); sumsq_set_workspace(nullptr);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -576,7 +580,7 @@ static void net_gru(mi_ctx* c, int n) {
     launch_gru_gates(c->gru_gi, c->gru_gh, c->h_masked, c->h_state, c->feat, n, H, c->stream);
 }
 
-static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = false) {
+static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = false, bool with_heads = true) {
     if (c->cfg.arch == MI_ARCH_IMPALA) {
         const float* prev = nullptr;
         for (int b = 0; b < 3; ++b) {
@@ -602,7 +606,7 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
         }
     }
     if (recurrent && c->gru_on) net_gru(c, n);
-    net_heads(c, n);
+    if (with_heads) net_heads(c, n);
 }
 
 // backward from dY (n x (A+1)); gradients accumulate into c->grads
@@ -672,6 +676,38 @@ int mi_policy_step(mi_ctx* c, int32_t t, uint64_t seed, const float* u, int64_t*
     if (act_out && !last) for (int e = 0; e < E; ++e) act_out[e] = c->h_i[e];
     if (logp_out && !last) memcpy(logp_out, c->h_f, (size_t)E * 4);
     if (value_out) memcpy(value_out, c->h_f + E, (size_t)E * 4);
+    return 0;
+}
+
+int mi_rollout_step(mi_ctx* c, int32_t t, const float* rew_prev, const float* done_prev, uint64_t seed, const float* u,
+                    int64_t* act_out, float* logp_out, float* value_out) {
+    ARG(c, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    const int E = c->E;
+    if (rew_prev || done_prev) {
+        ARG(rew_prev && done_prev && t >= 1, "rew_prev/done_prev come together and belong to step t-1");
+        memcpy(c->h_rd, rew_prev, (size_t)E * 4); memcpy(c->h_rd + E, done_prev, (size_t)E * 4);
+        HIPC(hipMemcpyAsync(c->d_rd, c->h_rd, (size_t)2 * E * 4, hipMemcpyHostToDevice, c->stream));
+        if (c->gru_on) HIPC(hipMemcpyAsync(c->d_done, c->d_rd + E, (size_t)E * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    const bool have_rd = rew_prev != nullptr;
+    InputSrc src{c->frames ? (const void*)c->frames : (const void*)c->obsf, nullptr, (long long)t * E};
+    const float* du = nullptr;
+    if (u) { HIPC(hipMemcpyAsync(c->d_u, u, (size_t)E * 4, hipMemcpyHostToDevice, c->stream)); du = c->d_u; }
+    c->prof.phase = 0;
+    net_forward(c, src, E, true, false);
+    const bool last = (t == c->T);
+    launch_heads_sample(c->feat, c->params + c->wh_off, c->params + c->bh_off, E, c->H, c->A, du, seed, (unsigned long long)t * E,
+                        last ? nullptr : c->act + (size_t)t * E, last ? nullptr : c->logp + (size_t)t * E, c->value + (size_t)t * E,
+                        c->d_pack, nullptr, have_rd ? c->d_rd : nullptr, have_rd ? c->rew + (size_t)(t - 1) * E : nullptr,
+                        have_rd ? c->done + (size_t)(t - 1) * E : nullptr, c->stream);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(c->h_pack, c->d_pack, (size_t)3 * E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));             // also covers the h_rd / u staging reuse
+    for (int e = 0; e < E; ++e) {
+        if (act_out && !last) act_out[e] = (int64_t)c->h_pack[3 * e];
+        if (logp_out && !last) logp_out[e] = c->h_pack[3 * e + 1];
+        if (value_out) value_out[e] = c->h_pack[3 * e + 2];
+    }
     return 0;
 }
 

@@ -35,9 +35,13 @@ __device__ __forceinline__ T block_sum256(T v, T* sbuf) {
 // Used for: embedder.fc, the policy/value heads and the MLP embedder (forward, dgrad, wgrad) --
 // nn.Linear in common/model.py:176,199 / :966-971 and common/policy.py:39-40,75,80.
 __device__ __forceinline__ unsigned short f2bf_g(float x) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ float gemm_ld(const float* p, long long o, int bf16) {
+    return bf16 ? __uint_as_float(((unsigned)((const unsigned short*)p)[o]) << 16) : p[o];
+}
+// K tile 32; the next tile's global loads are issued into registers before the MFMAs of the current one.
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int k_chunk, float* ws) {
-    __shared__ __attribute__((aligned(16))) float As[64 * 20];
-    __shared__ __attribute__((aligned(16))) float Bs[64 * 20];
+    __shared__ __attribute__((aligned(16))) float As[64 * 36];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * 36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4, wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -48,42 +52,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int k_chunk, floa
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool a_kc = (g.sak == 1), b_kc = (g.sbk == 1);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        __syncthreads();
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
             const int l = tid + e * 256;
             int m, k;
-            if (a_kc) { m = l >> 4; k = l & 15; } else { m = l & 63; k = l >> 6; }
+            if (a_kc) { m = l >> 5; k = l & 31; } else { m = l & 63; k = l >> 6; }
             float v = 0.f;
-            if (m0 + m < g.M && k0 + k < kend) {
-                const long long o = (long long)(m0 + m) * g.sam + (long long)(k0 + k) * g.sak;
-                v = g.a_bf16 ? __uint_as_float(((unsigned)((const unsigned short*)g.A)[o]) << 16) : g.A[o];
-                if (g.relu_a) v = fmaxf(v, 0.f);
-            }
-            As[m * 20 + k] = v;
+            if (m0 + m < g.M && k0 + k < kend) v = gemm_ld(g.A, (long long)(m0 + m) * g.sam + (long long)(k0 + k) * g.sak, g.a_bf16);
+            ra[e] = v;
             int n;
-            if (b_kc) { n = l >> 4; k = l & 15; } else { n = l & 63; k = l >> 6; }
+            if (b_kc) { n = l >> 5; k = l & 31; } else { n = l & 63; k = l >> 6; }
             v = 0.f;
-            if (n0 + n < g.N && k0 + k < kend) {
-                const long long o = (long long)(k0 + k) * g.sbk + (long long)(n0 + n) * g.sbn;
-                v = g.b_bf16 ? __uint_as_float(((unsigned)((const unsigned short*)g.B)[o]) << 16) : g.B[o];
-                if (g.relu_b) v = fmaxf(v, 0.f);
-            }
-            Bs[n * 20 + k] = v;
+            if (n0 + n < g.N && k0 + k < kend) v = gemm_ld(g.B, (long long)(k0 + k) * g.sbk + (long long)(n0 + n) * g.sbn, g.b_bf16);
+            rb[e] = v;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int l = tid + e * 256;
+            int m, k;
+            if (a_kc) { m = l >> 5; k = l & 31; } else { m = l & 63; k = l >> 6; }
+            As[m * 36 + k] = g.relu_a ? fmaxf(ra[e], 0.f) : ra[e];
+            int n;
+            if (b_kc) { n = l >> 5; k = l & 31; } else { n = l & 63; k = l >> 6; }
+            Bs[n * 36 + k] = g.relu_b ? fmaxf(rb[e], 0.f) : rb[e];
         }
         __syncthreads();
-        f32x4 av[2], bv[2];
+        if (k0 + 32 < kend) fetch(k0 + 32);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) av[a] = *(const f32x4*)(As + (wm * 32 + a * 16 + i) * 20 + q * 4);
+        for (int h = 0; h < 2; ++h) {
+            f32x4 av[2], bv[2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) bv[b] = *(const f32x4*)(Bs + (wn * 32 + b * 16 + i) * 20 + q * 4);
+            for (int a = 0; a < 2; ++a) av[a] = *(const f32x4*)(As + (wm * 32 + a * 16 + i) * 36 + q * 4 + h * 16);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int b = 0; b < 2; ++b) bv[b] = *(const f32x4*)(Bs + (wn * 32 + b * 16 + i) * 36 + q * 4 + h * 16);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(av[a][e], bv[b][e], acc[a][b]);
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(av[a][e], bv[b][e], acc[a][b]);
+        }
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -98,10 +112,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int k_chunk, floa
                     const long long o = (long long)m * g.ldc + n;
                     if (g.bias) v += g.bias[n];
                     if (g.relu_out) v = fmaxf(v, 0.f);
-                    if (g.mask) {
-                        const float mv = g.mask_bf16 ? __uint_as_float(((unsigned)((const unsigned short*)g.mask)[o]) << 16) : g.mask[o];
-                        v = mv > 0.f ? v : 0.f;
-                    }
+                    if (g.mask) v = gemm_ld(g.mask, o, g.mask_bf16) > 0.f ? v : 0.f;
                     if (g.c_bf16) { ((unsigned short*)g.C)[o] = f2bf_g(v); continue; }
                     if (g.accumulate) v += g.C[o];
                     g.C[o] = v;
@@ -143,7 +154,7 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
         if (split < 1) split = 1;
         while (split > 1 && (size_t)split * g.M * g.N > g_gemm_ws_floats) --split;
     }
-    int k_chunk = ((g.K + split - 1) / split + 15) / 16 * 16;
+    int k_chunk = ((g.K + split - 1) / split + 31) / 32 * 32;
     if (split == 1) {
         hipLaunchKernelGGL(gemm_kernel, dim3(tn, tm, 1), dim3(256), 0, st, g, k_chunk, (float*)nullptr);
     } else {
@@ -336,27 +347,27 @@ void launch_maxpool_bwd(const float* dout, const uint8_t* arg, float* din, int n
 }
 
 // ------------------------------------------------------------------------------------------ slab / column reductions
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ partial, int nslab, int slab_len,
-                                                           float* dst_w, int n_w, float* dst_b, int n_b) {
-    __shared__ float sh[8][33];
-    const int ex = threadIdx.x & 31, g = threadIdx.x >> 5;
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ partial, int nslab, int slab_len,
+                                                            float* dst_w, int n_w, float* dst_b, int n_b) {
+    __shared__ float sh[32][33];
+    const int ex = threadIdx.x & 31, g = threadIdx.x >> 5;        // 32 elements x 32 slab groups
     const int e = blockIdx.x * 32 + ex;
     float s = 0.f;
     if (e < slab_len)
-        for (int b = g; b < nslab; b += 8) s += partial[(long long)b * slab_len + e];
+        for (int b = g; b < nslab; b += 32) s += partial[(long long)b * slab_len + e];
     sh[g][ex] = s;
     __syncthreads();
     if (g == 0 && e < slab_len) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][ex];
+        for (int k = 0; k < 32; ++k) t += sh[k][ex];
         if (e < n_w) dst_w[e] += t;
         else if (e - n_w < n_b) dst_b[e - n_w] += t;
     }
 }
 void launch_reduce_slabs(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b, hipStream_t st) {
     if (nslab <= 0) return;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((slab_len + 31) / 32), dim3(256), 0, st, partial, nslab, slab_len, dst_w, n_w, dst_b, n_b);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((slab_len + 31) / 32), dim3(1024), 0, st, partial, nslab, slab_len, dst_w, n_w, dst_b, n_b);
 }
 
 // db[n] += sum_m dY[m][n]   (bias gradients of the linear layers); 64 row groups x fixed order
@@ -400,6 +411,7 @@ void launch_fill(float* p, long long n, float v, hipStream_t st) {
 // agents/ppo.py:131-169 + cross_batch_entropy (common/misc_util.py:42-51), forward statistics and
 // the analytic gradient wrt (logits, value).  One thread per sample; A <= 16.
 #define MAXA 16
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr);
 struct SampleTerms {
     float lp[MAXA], p[MAXA];
     float H, ratio, adv, surr1, surr2, v, oldv, ret, vclip, vs1, vs2;
@@ -632,21 +644,6 @@ void launch_advnorm_apply(float* adv, int n, const double* stats3, hipStream_t s
 // ------------------------------------------------------------------------------------------ rollout head: sample
 // agents/ppo.py:77-79: dist.sample(), dist.log_prob(act).  Inverse-CDF over the A probabilities with a
 // uniform from a caller-supplied array (tests) or Philox4x32-10 keyed by (seed, counter + env).
-__device__ __forceinline__ void philox_round(uint32_t* c, uint32_t* k) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
-    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-}
-__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr) {
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-    for (int r = 0; r < 10; ++r) philox_round(c, k);
-    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);     // [0,1), 24 bits
-}
 __global__ void sample_kernel(const float* hout, int n, int A, const float* u, unsigned long long seed,
                               unsigned long long ctr, int32_t* act, float* logp, float* value) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -678,6 +675,74 @@ void launch_logp_all(const float* hout, int n, int A, float* lp_out, float* valu
     if (n <= 0) return;
     hipLaunchKernelGGL(logp_all_kernel, dim3((n + 63) / 64), dim3(64), 0, st, hout, n, A, lp_out, value_out);
 }
+__device__ __forceinline__ void philox_round(uint32_t* c, uint32_t* k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);     // [0,1), 24 bits
+}
+// Rollout head, fused: policy/value heads (common/policy.py:74-80) + log-softmax + sample + log_prob
+// (agents/ppo.py:77-79) for one env per wave; results also packed [n][3] = {act, logp, value} for ONE read-back.
+__global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restrict__ feat, const float* __restrict__ Wh,
+                                                           const float* __restrict__ bh, int n, int H, int A, const float* u,
+                                                           unsigned long long seed, unsigned long long ctr, int32_t* act,
+                                                           float* logp, float* value, float* pack, float* hout,
+                                                           const float* rd, float* rew_dst, float* done_dst) {
+    const int lane = threadIdx.x & 63, e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= n) return;                                   // whole waves exit together
+    if (rd && lane == 1) { rew_dst[e] = rd[e]; done_dst[e] = rd[n + e]; }   // previous step's reward / done into the (T,E) arrays
+    float z[MAXA + 1];                                   // statically indexed everywhere (a runtime-indexed array would live in scratch)
+#pragma unroll
+    for (int o = 0; o <= MAXA; ++o) z[o] = 0.f;
+    for (int k = lane; k < H; k += 64) {
+        const float f = feat[(long long)e * H + k];
+#pragma unroll
+        for (int o = 0; o <= MAXA; ++o)
+            if (o <= A) z[o] += f * Wh[(long long)o * H + k];
+    }
+#pragma unroll
+    for (int o = 0; o <= MAXA; ++o) {
+        float v = z[o];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+        z[o] = (o <= A) ? v + bh[o] : 0.f;
+    }
+    if (lane != 0) return;
+    float lp[MAXA], p[MAXA];
+    log_softmax_twice(z, A, lp, p);
+    const float uu = u ? u[e] : philox_uniform(seed, ctr + e);
+    float cdf = 0.f;
+    int a_sel = 0;
+    for (int k = 0; k < A; ++k) { cdf += expf(lp[k]); if (cdf <= uu) a_sel = k + 1; }
+    if (a_sel > A - 1) a_sel = A - 1;
+    if (act) act[e] = a_sel;
+    if (logp) logp[e] = lp[a_sel];
+    float val = 0.f;
+#pragma unroll
+    for (int o = 0; o <= MAXA; ++o) if (o == A) val = z[o];
+    if (value) value[e] = val;
+    if (pack) { pack[e * 3] = (float)a_sel; pack[e * 3 + 1] = lp[a_sel]; pack[e * 3 + 2] = val; }
+    if (hout) {
+#pragma unroll
+        for (int o = 0; o <= MAXA; ++o) if (o <= A) hout[(long long)e * (A + 1) + o] = z[o];
+    }
+}
+void launch_heads_sample(const float* feat, const float* Wh, const float* bh, int n, int H, int A, const float* u,
+                         unsigned long long seed, unsigned long long ctr, int32_t* act, float* logp, float* value, float* pack,
+                         float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(heads_sample_kernel, dim3((n + 3) / 4), dim3(256), 0, st, feat, Wh, bh, n, H, A, u, seed, ctr, act, logp, value, pack, hout,
+                       rd, rew_dst, done_dst);
+}
 void launch_sample(const float* hout, int n, int A, const float* u, unsigned long long seed, unsigned long long ctr,
                    int32_t* act, float* logp, float* value, hipStream_t st) {
     if (n <= 0) return;
@@ -697,8 +762,25 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const float* g, long long n
     __syncthreads();
     if (tid == 0) { double t = 0.0; for (int k = 0; k < 16; ++k) t += sb[k]; out[0] = t; }
 }
+// 128 fixed chunks -> partials -> fixed-order final sum (deterministic, and 100x the bandwidth of one workgroup)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long long n, double* part) {
+    __shared__ double sb[4];
+    const long long chunk = (n + gridDim.x - 1) / gridDim.x, beg = (long long)blockIdx.x * chunk;
+    const long long end = beg + chunk < n ? beg + chunk : n;
+    double s = 0.0;
+    for (long long k = beg + threadIdx.x; k < end; k += 256) { const double x = (double)g[k]; s += x * x; }
+    const double t = block_sum256(s, sb);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void sumsq_final_kernel(const double* part, int n, double* out) {
+    if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < n; ++k) t += part[k]; out[0] = t; }
+}
+static double* g_sumsq_part = nullptr;
+void sumsq_set_workspace(double* ws) { g_sumsq_part = ws; }      // >= 128 doubles
 void launch_sumsq(const float* g, long long n, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, st, g, n, out);
+    if (!g_sumsq_part) { hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, st, g, n, out); return; }
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(128), dim3(256), 0, st, g, n, g_sumsq_part);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, (const double*)g_sumsq_part, 128, out);
 }
 __global__ void adam_kernel(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr_unused,
                             float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float* gnorm_out) {

@@ -39,7 +39,7 @@ def lib_path():
 
 EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_param_count mi_set_params "
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
-           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_predict_staged mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
+           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_predict_staged mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_optimizer_step mi_loss_log_read mi_device_ptr "
            "mi_set_multirank mi_minibatch_finish mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
 
@@ -194,6 +194,16 @@ class Engine:
         logp = np.empty(self.E, np.float32)
         val = np.empty(self.E, np.float32)
         self._chk(self.lib.mi_policy_step(self._ctx, C.c_int32(t), C.c_uint64(seed), _fp(u), _fp(act), _fp(logp), _fp(val)))
+        return act, logp, val
+
+    def rollout_step(self, t, rew_prev=None, done_prev=None, seed=0, u=None):
+        """store(t-1)'s reward/done + policy step on slot t in one call (one packed upload, one packed read-back)."""
+        u = None if u is None else _f32(u)
+        rew_prev = None if rew_prev is None else _f32(rew_prev)
+        done_prev = None if done_prev is None else _f32(done_prev)
+        act, logp, val = np.empty(self.E, np.int64), np.empty(self.E, np.float32), np.empty(self.E, np.float32)
+        self._chk(self.lib.mi_rollout_step(self._ctx, C.c_int32(t), _fp(rew_prev), _fp(done_prev), C.c_uint64(seed), _fp(u),
+                                           _fp(act), _fp(logp), _fp(val)))
         return act, logp, val
 
     def predict_staged(self, obs, seed=0, counter=0, u=None):
