@@ -67,6 +67,43 @@ def cpu_baseline(T, n_samples, threads):
                        f"oracle, extrapolated to (1+1/T) forwards + 3 update passes per env step")
 
 
+def rocprof_name(cls, precision):
+    """kernel class of the live profiler -> substring of the rocprofv3 kernel name (template arguments)."""
+    kind, cin, cout, hw = cls.split("_")[1], *[int(x) for x in cls.split("_")[2:5]]
+    if cin == 3:
+        return ("conv3x3_wgrad_kernel<WgCfg<3, 4, 16, 64" if kind == "wgrad" else "conv3x3_kernel<FwdCfg<3, 4, 16, 64")
+    if precision == "bf16":
+        if kind == "wgrad":
+            return f"conv3x3_wgrad_bf16_kernel<WbCfg<{cin}, {cout}, {hw},"
+        return f"conv3x3_bf16_kernel<BfCfg<{cin}, {cout}, {hw}," if kind == "fwd" else f"conv3x3_bf16_kernel<BfCfg<{cout}, {cin}, {hw},"
+    if kind == "wgrad":
+        return f"conv3x3_wgrad_kernel<WgCfg<{cin}, {cin}, {cout}, {hw},"
+    return f"conv3x3_kernel<FwdCfg<{cin}, {cin}, {cout}, {hw}," if kind == "fwd" else f"conv3x3_kernel<FwdCfg<{cout}, {cout}, {cin}, {hw},"
+
+
+def pmc_traffic(cls, precision):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the
+    gfx950 correction + WRITE_SIZE; profiles/r01_pmc_<precision>.json, collected on 8192-sample launches by
+    scratch/pmc_workload.py).  None when no committed counter summary matches."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_{precision}.json")))
+    except Exception:
+        return None
+    key = rocprof_name(cls, precision)
+    for name, v in tab.items():
+        if key not in name:
+            continue
+        if "wgrad" not in cls and "3_16_64" not in cls:
+            args = name[name.index("Cfg<") + 4:name.index(">")].replace(" ", "").split(",")
+            transw = args[6] if "BfCfg" in name else args[8]
+            if (transw == "true") != ("dgrad" in cls):
+                continue
+        return dict(bytes_per_launch=(v["hbm_read_MB_per_call"] + v["hbm_write_MB_per_call"]) * 1048576.0,
+                    read_MB=v["hbm_read_MB_per_call"], write_MB=v["hbm_write_MB_per_call"],
+                    source=f"profiles/r01_pmc_{precision}.json", rocprof_kernel=name)
+    return None
+
+
 def host_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a 1-GPU box exposes all
     host CPUs but grants a 16-core share); oversubscribing the quota makes the CPU leg slower, not faster."""
@@ -92,7 +129,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
                     help="activation storage: fp32 = parity mode; bf16 = BASELINE config 3 (bf16 storage + bf16 MFMA fwd/dgrad)")
     ap.add_argument("--profile-rollout", action="store_true", help="bracket the rollout-phase launches with HIP events too")
     ap.add_argument("--h2d", action="store_true", help="also upload the E frames of every rollout step from pinned host memory")
@@ -187,16 +224,18 @@ def main():
         if dom is not None:
             sec = dom["ms"] / 1e3
             gbs, tfs = dom["bytes"] / sec / 1e9, dom["flops"] / sec / 1e12
-            # matrix peak of the instruction this kernel issues: weight gradients and block1.conv stay on the fp32
-            # MFMA in both modes; the bf16 mode's forward / dgrad convs run v_mfma_f32_16x16x32_bf16
-            on_bf16_mfma = args.precision == "bf16" and ("wgrad" not in dom["kernel"]) and ("3_16_64" not in dom["kernel"])
+            # matrix peak of the instruction this kernel issues: block1.conv (3 input channels) stays on the fp32 MFMA
+            # in both modes; every other conv of the bf16 mode runs v_mfma_f32_16x16x32_bf16
+            on_bf16_mfma = args.precision == "bf16" and ("3_16_64" not in dom["kernel"])
             mpeak = MFMA_BF16_PEAK_TF if on_bf16_mfma else MFMA_F32_PEAK_TF
             f_h, f_m = gbs / HBM_PEAK_GBS, tfs / mpeak
             bound = "mfma" if f_m >= f_h else "hbm"
             roof = dict(bound=bound, achieved=(tfs if bound == "mfma" else gbs), peak=(mpeak if bound == "mfma" else HBM_PEAK_GBS),
-                        unit=("TFLOP/s" if bound == "mfma" else "GB/s"), frac=(f_m if bound == "mfma" else f_h), traffic=None,
+                        unit=("TFLOP/s" if bound == "mfma" else "GB/s"), frac=(f_m if bound == "mfma" else f_h),
+                        traffic=pmc_traffic(dom["kernel"], args.precision),
                         kernel=dom["kernel"], avg_launch_ms=dom["ms"] / dom["launches"], launches=dom["launches"],
-                        samples_per_launch=dom["samples"] / dom["launches"], hbm_GBps=gbs, hbm_frac=f_h, mfma_TFps=tfs, mfma_frac=f_m,
+                        samples_per_launch=dom["samples"] / dom["launches"], algorithmic_bytes_per_launch=dom["bytes"] / dom["launches"],
+                        hbm_GBps=gbs, hbm_frac=f_h, mfma_TFps=tfs, mfma_frac=f_m, mfma_peak_TFps=mpeak,
                         share_of_timed_region=dom["ms"] / 1e3 / dt)
         out = {"metric": "env steps/sec (whole node), coinrun hard-500 IMPALA-CNN PPO", "value": value, "unit": "env steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

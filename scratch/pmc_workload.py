@@ -11,7 +11,8 @@ from common.policy import CategoricalPolicy
 T, E, A, B = 32, 256, 15, 8192
 torch.manual_seed(6033)
 pol = CategoricalPolicy(ImpalaModel(3), False, A)
-eng = Engine("impala", T, E, A, B)
+PREC = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+eng = Engine("impala", T, E, A, B, precision=PREC)
 eng.set_params(layout.flatten(layout.impala_param_shapes(A), {k: v.detach().numpy() for k, v in pol.state_dict().items()}))
 rng = np.random.default_rng(0)
 for t in range(T + 1):
