@@ -23,12 +23,14 @@ template <int CIN_, int COUT_, int HW_, int TH_, int TW_, int NIMG_, bool TRANSW
 struct BfCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, HW = HW_, TH = TH_, TW = TW_, NIMG = NIMG_;
     static constexpr bool TRANSW = TRANSW_;
-    static constexpr int S = CIN + 8;                        // bf16 elements per staged pixel (16-B aligned rows)
+    // bf16 elements per staged pixel / per filter row: strides for which every ds_read_b128 lane group is
+    // bank-conflict free (brute-forced over the gfx950 lane-group / 64-bank rule; CIN+8 gave 2-way conflicts)
+    static constexpr int S = (CIN == 16) ? 16 : 48;
     static constexpr int PH = TH + 2, PW = TW + 2;
     static constexpr int NPIX = NIMG * PH * PW;
     static constexpr int IN_ELEMS = ((NPIX * S + 7) / 8) * 8;
     static constexpr int NK = (CIN == 32) ? 9 : 5;           // MFMAs (K = 32 each) per (pixel tile, channel block)
-    static constexpr int WS = NK * 32 + 8;                   // bf16 elements per output channel of the filter bank
+    static constexpr int WS = NK * 32 + 16;                  // bf16 elements per output channel of the filter bank
     static constexpr int W_ELEMS = COUT * WS;
     static constexpr int NMT = NIMG * TH * TW / 16, MT = NMT / 4, NB = COUT / 16;
     static constexpr int TPI_X = HW / TW, TPI = (HW / TH) * (HW / TW);
@@ -222,7 +224,9 @@ typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 template <int CIN_, int COUT_, int HW_, int TH_, int TW_, int NIMG_>
 struct WbCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, HW = HW_, TH = TH_, TW = TW_, NIMG = NIMG_;
-    static constexpr int S = CIN + 8, SO = COUT + 8;          // bf16 elements per staged pixel (input tile / dOut tile)
+    // bf16 elements per staged pixel (input tile / dOut tile): with the pixel order below the 8 rows a half-wave's
+    // ds_read_b64_tr_b16 touches are 8 consecutive pixels, conflict-free when the row stride is 32 B x odd
+    static constexpr int S = (CIN == 16) ? 16 : 48, SO = (COUT == 16) ? 16 : 48;
     static constexpr int PH = TH + 2, PW = TW + 2, NPIX = NIMG * PH * PW, NT = NIMG * TH * TW;
     static constexpr int IN_ELEMS = ((NPIX * S + 7) / 8) * 8, DO_ELEMS = ((NT * SO + 7) / 8) * 8;
     static constexpr int NCB = COUT / 16, NIB = CIN / 16, NSTEP = NT / 32;
@@ -304,11 +308,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
         if (work + (int)gridDim.x < nwork) { coords(work + gridDim.x, img0, ty0, tx0); load(img0, ty0, tx0); }
 
         for (int t = wave; t < C::NSTEP; t += 4) {
-            // this lane's two source rows (pixels) of the 4x16 transpose blocks: k = 8*kq + 4*h + rq
+            // this lane's two source rows (pixels) of the 4x16 transpose blocks.  MFMA k index = 8*kq + 4*h + rq; the
+            // pixel it stands for is a free (A/B-consistent) permutation: 16*(kq>>1) + 8*h + 4*(kq&1) + rq
             int drow[2], irow[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int pl = 32 * t + 8 * kq + 4 * h + rq, y = pl / C::TW, x = pl % C::TW;
+                const int pl = 32 * t + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq, y = pl / C::TW, x = pl % C::TW;
                 drow[h] = pl * C::SO + 4 * cp;
                 irow[h] = (((y / C::TH) * C::PH + (y % C::TH)) * C::PW + x) * C::S + 4 * cp;
             }
