@@ -126,3 +126,10 @@ void launch_adam(float* p, float* g, float* m, float* v, long long n, const doub
 void launch_fill(float* p, long long n, float v, hipStream_t st);
 void launch_mask_rows(const float* h, const float* done, float* out, int n, int H, hipStream_t st);   // out = h * (1 - done[row])
 void launch_gru_gates(const float* gi, const float* gh, const float* hm, float* h_out, float* feat_out, int n, int H, hipStream_t st);
+
+// ---------------------------------------------------------------- embedder.fc on the bf16 matrix cores (fc_bf16.hip)
+struct FcNtArgs;
+void launch_fc_pack(const float* w, unsigned short* wp, unsigned short* wt, int N, int K, hipStream_t st);
+void launch_fc_fwd_bf16(const void* x_bf16, const unsigned short* wp, const float* bias, float* y, int n, hipStream_t st);
+void launch_fc_dgrad_bf16(const float* dy, const unsigned short* wt, const void* mask_bf16, void* dx_bf16, int n, hipStream_t st);
+void launch_fc_tn(const float* A, const unsigned short* B, float* gW, float* ws, size_t ws_floats, int M, int N, int K, hipStream_t st);

@@ -95,6 +95,8 @@ struct mi_ctx {
     float *loss_partial, *loss_stats, *loss_log; int log_count, log_cap;
     double* sumsq; float* gnorm;
     float* d_u; float* d_lp;
+    unsigned short *fc_wp, *fc_wt;            // bf16 mode: packed fc.weight images ([256][2048] and [2048][256])
+    bool fc_packed_valid;
     float *d_pack, *h_pack, *h_rd, *d_rd;     // packed rollout read-back {act,logp,value} x E ; packed {rew,done} upload
     int32_t* s_act; float *s_logp, *s_val; bool staged_valid;
     // recurrent rollout (GRU cell, never trained)
@@ -310,6 +312,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
     c->multirank = 0; c->pending_n = -1;
+    c->fc_wp = c->fc_wt = nullptr; c->fc_packed_valid = false;
+    if (c->bf) { HIPC(dalloc(&c->fc_wp, (size_t)256 * 2048)); HIPC(dalloc(&c->fc_wt, (size_t)256 * 2048)); }
     c->gru_on = false; c->gru_wih = c->gru_whh = c->gru_bih = c->gru_bhh = c->h_state = c->h_masked = c->gru_gi = c->gru_gh = c->d_done = nullptr;
     HIPC(hipDeviceSynchronize());
     *out = c;
@@ -332,6 +336,7 @@ int mi_destroy(mi_ctx* c) {
     if (c->frames) hipFree(c->frames);
     if (c->stage_frames) hipFree(c->stage_frames);
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
+    if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
     hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
@@ -353,7 +358,7 @@ void mi_host_free(void* p) { if (p) hipHostFree(p); }
 int mi_sync(mi_ctx* c) { ARG(c, "ctx"); HIPC(hipStreamSynchronize(c->stream)); return 0; }
 
 int64_t mi_param_count(mi_ctx* c) { return c ? c->n_params : -1; }
-int mi_set_params(mi_ctx* c, const float* flat, int64_t n) { ARG(c && flat, "null"); return upload_flat(c, c->params, flat, n); }
+int mi_set_params(mi_ctx* c, const float* flat, int64_t n) { ARG(c && flat, "null"); c->fc_packed_valid = false; return upload_flat(c, c->params, flat, n); }
 int mi_get_params(mi_ctx* c, float* flat, int64_t n) { ARG(c && flat, "null"); return download_flat(c, c->params, flat, n); }
 int mi_get_grads(mi_ctx* c, float* flat, int64_t n) { ARG(c && flat, "null"); return download_flat(c, c->grads, flat, n); }
 int mi_set_adam_state(mi_ctx* c, const float* m, const float* v, int64_t n) {
@@ -580,6 +585,10 @@ static void net_gru(mi_ctx* c, int n) {
     launch_gru_gates(c->gru_gi, c->gru_gh, c->h_masked, c->h_state, c->feat, n, H, c->stream);
 }
 
+static void fc_refresh(mi_ctx* c) {
+    if (c->bf && !c->fc_packed_valid) { launch_fc_pack(c->params + c->fc.w_off, c->fc_wp, c->fc_wt, 256, 2048, c->stream); c->fc_packed_valid = true; }
+}
+
 static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = false, bool with_heads = true) {
     if (c->cfg.arch == MI_ARCH_IMPALA) {
         const float* prev = nullptr;
@@ -596,7 +605,12 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
             conv_fwd(c, L[4], k.A2, nullptr, 1, k.P1, k.P2, n);
             prev = k.P2;
         }
-        linear_fwd(c, c->blk[2].P2, 1, c->params + c->fc.w_off, c->params + c->fc.b_off, c->feat, n, 2048, c->H, 1, c->bf);
+        if (c->bf && n >= 1024) {               // update-sized batches: bf16 matrix cores (fc_bf16.hip)
+            fc_refresh(c);
+            ProfScope ps(c, PC_GEMM, n, 2.0 * n * 2048 + 2.0 * 2048 * 256 + 4.0 * n * 256, 2.0 * n * 2048 * 256);
+            launch_fc_fwd_bf16(c->blk[2].P2, c->fc_wp, c->params + c->fc.b_off, c->feat, n, c->stream);
+        } else
+            linear_fwd(c, c->blk[2].P2, 1, c->params + c->fc.w_off, c->params + c->fc.b_off, c->feat, n, 2048, c->H, 1, c->bf);
     } else {
         launch_gather_rows((const float*)src.base, src.idx, src.first, c->mlp_act[0], n, c->cfg.obs_dim, c->stream);
         const size_t L = c->mlp.size();
@@ -626,11 +640,22 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         }
         return;
     }
-    linear_wgrad(c, c->dfeat, c->blk[2].P2, 1, c->grads + c->fc.w_off, c->grads + c->fc.b_off, n, 2048, c->H, c->bf);
+    const bool fc16 = c->bf && n >= 1024;
+    if (fc16) {
+        fc_refresh(c);
+        { ProfScope ps(c, PC_GEMM, n, 2.0 * n * 2048 + 4.0 * n * 256 + 4.0 * 2048 * 256, 2.0 * n * 2048 * 256);
+          launch_fc_tn(c->dfeat, (const unsigned short*)c->blk[2].P2, c->grads + c->fc.w_off, c->gemm_ws, (size_t)8 << 20, 256, 2048, n, c->stream); }
+        launch_colsum_acc(c->dfeat, n, 256, 256, c->grads + c->fc.b_off, c->stream);
+    } else
+        linear_wgrad(c, c->dfeat, c->blk[2].P2, 1, c->grads + c->fc.w_off, c->grads + c->fc.b_off, n, 2048, c->H, c->bf);
     float* Gout = c->GP[0];
     float* Ga = c->GP[1];
     float* Gb = c->GP[2];
-    linear_dgrad(c, c->dfeat, c->params + c->fc.w_off, c->blk[2].P2, Gout, n, 2048, c->H, c->bf);
+    if (fc16) {
+        ProfScope ps(c, PC_GEMM, n, 4.0 * n * 256 + 2.0 * 2048 * 256 + 2.0 * 2.0 * n * 2048, 2.0 * n * 2048 * 256);
+        launch_fc_dgrad_bf16(c->dfeat, c->fc_wt, c->blk[2].P2, Gout, n, c->stream);
+    } else
+        linear_dgrad(c, c->dfeat, c->params + c->fc.w_off, c->blk[2].P2, Gout, n, 2048, c->H, c->bf);
     for (int b = 2; b >= 0; --b) {
         Block& k = c->blk[b];
         const ConvLayer* L = &c->convs[b * 5];
@@ -904,6 +929,7 @@ int mi_optimizer_step(mi_ctx* c, float lr, float max_norm, int32_t step, float* 
     launch_sumsq(c->grads, c->n_params, c->sumsq, c->stream);
     launch_adam(c->params, c->grads, c->adam_m, c->adam_v, c->n_params, c->sumsq, max_norm, lr, (float)b1, (float)b2, 1e-5f,
                 step_size, bc2_sqrt, c->gnorm, c->stream);
+    c->fc_packed_valid = false;
     HIPC(hipGetLastError());
     if (gnorm_out) {
         HIPC(hipMemcpyAsync(c->h_f, c->gnorm, 4, hipMemcpyDeviceToHost, c->stream));

@@ -1,0 +1,243 @@
+// embedder.fc (2048 -> 256, common/model.py:176,199-200) on the bf16 matrix cores for the bf16 mode: forward,
+// data gradient and weight gradient.  The activations (block3 output, bf16 NHWC = the flattened 2048 features) are
+// read as stored; the fp32 gradient of the 256 features is rounded to bf16 while staged; fc.weight is kept as two
+// packed bf16 images ([256][2048] for forward, [2048][256] for dgrad) refreshed after every optimizer step.
+//   NT kernel : C[M][N] = A[M][K] * Bp[N][K]^T         (forward: +bias, ReLU, fp32 out; dgrad: ReLU mask, bf16 out)
+//   TN kernel : gW[M][N] += A[K][M]^T * relu(B[K][N])   (weight gradient; both operands K(=batch)-major in memory ->
+//               ds_read_b64_tr_b16 fragments; split over the batch, slabs summed in fixed order)
+#include "common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned short fc_f2bf(float x) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ unsigned fc_pack2(float lo, float hi) { return (unsigned)fc_f2bf(lo) | ((unsigned)fc_f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned fc_relu2(unsigned w) { const unsigned neg = (w >> 15) & 0x00010001u; return w & ~(neg * 0xFFFFu); }
+
+__global__ void fc_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, unsigned short* __restrict__ wt, int N, int K) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * K) return;
+    const unsigned short h = fc_f2bf(w[e]);
+    wp[e] = h;                                   // [n][k]
+    wt[(long long)(e % K) * N + e / K] = h;      // [k][n]
+}
+void launch_fc_pack(const float* w, unsigned short* wp, unsigned short* wt, int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(fc_pack_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, w, wp, wt, N, K);
+}
+
+// ------------------------------------------------------------------------------------------ NT
+struct FcNtArgs {
+    const void* A; const unsigned short* Bp; void* C;
+    int M, N, K;
+    const float* bias; const unsigned short* mask;      // mask: same shape as C (bf16), ReLU mask source
+    int a_f32, relu_a, relu_out, c_bf16;
+};
+constexpr int NT_LD = 80;                                // LDS row stride (bf16 elements): 10 x 16-B slots, conflict free
+template <bool A_F32>
+__global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[128 * NT_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[64 * NT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 64;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 ra[4], rb[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                    // A tile: 128 rows x 8 chunks of 8 elements
+            const int l = tid + e * 256, r = l >> 3, c8 = l & 7;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (m0 + r < g.M) {
+                if constexpr (A_F32) {
+                    const float* p = (const float*)g.A + (long long)(m0 + r) * g.K + k0 + c8 * 8;
+                    const f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 4);
+                    v = (uint4){fc_pack2(lo.x, lo.y), fc_pack2(lo.z, lo.w), fc_pack2(hi.x, hi.y), fc_pack2(hi.z, hi.w)};
+                } else {
+                    v = *(const uint4*)((const unsigned short*)g.A + (long long)(m0 + r) * g.K + k0 + c8 * 8);
+                }
+            }
+            ra[e] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                    // B tile: 64 rows x 8 chunks
+            const int l = tid + e * 256, r = l >> 3, c8 = l & 7;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (n0 + r < g.N) v = *(const uint4*)(g.Bp + (long long)(n0 + r) * g.K + k0 + c8 * 8);
+            rb[e] = v;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < g.K; k0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int l = tid + e * 256;
+            uint4 v = ra[e];
+            if (g.relu_a) { v.x = fc_relu2(v.x); v.y = fc_relu2(v.y); v.z = fc_relu2(v.z); v.w = fc_relu2(v.w); }
+            *(uint4*)(As + (l >> 3) * NT_LD + (l & 7) * 8) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { const int l = tid + e * 256; *(uint4*)(Bs + (l >> 3) * NT_LD + (l & 7) * 8) = rb[e]; }
+        __syncthreads();
+        if (k0 + 64 < g.K) fetch(k0 + 64);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 av[2], bv[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = *(const bf16x8*)(As + (wave * 32 + a * 16 + i) * NT_LD + ks * 32 + kq * 8);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = *(const bf16x8*)(Bs + (b * 16 + i) * NT_LD + ks * 32 + kq * 8);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = MFMA_BF16(av[a], bv[b], acc[a][b]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wave * 32 + a * 16 + kq * 4 + r, n = n0 + b * 16 + i;
+                if (m < g.M && n < g.N) {
+                    const long long o = (long long)m * g.N + n;
+                    float v = acc[a][b][r];
+                    if (g.bias) v += g.bias[n];
+                    if (g.relu_out) v = fmaxf(v, 0.f);
+                    if (g.mask) v = (g.mask[o] & 0x8000u) || g.mask[o] == 0 ? 0.f : v;      // mask > 0  (bf16 bits)
+                    if (g.c_bf16) ((unsigned short*)g.C)[o] = fc_f2bf(v); else ((float*)g.C)[o] = v;
+                }
+            }
+}
+void launch_fc_nt(const FcNtArgs& g, hipStream_t st) {
+    if (g.M <= 0) return;
+    dim3 grid((g.N + 63) / 64, (g.M + 127) / 128);
+    if (g.a_f32) hipLaunchKernelGGL(fc_nt_kernel<true>, grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(fc_nt_kernel<false>, grid, dim3(256), 0, st, g);
+}
+
+// ------------------------------------------------------------------------------------------ TN (weight gradient)
+// gW[m][n] (+)= sum_k A[k][m] * relu(B[k][n]);  A fp32 [K][M] (rounded to bf16), B bf16 [K][N]; tile 64(M) x 128(N),
+// K tile 64; the 8 rows a half-wave's transpose read touches are 8 consecutive k (same permutation as the conv wgrad).
+constexpr int TN_LDA = 80, TN_LDB = 144;                 // 16 x odd elements: conflict-free transpose reads
+__global__ __launch_bounds__(256) void fc_tn_kernel(const float* __restrict__ A, const unsigned short* __restrict__ B, float* __restrict__ ws,
+                                                    int M, int N, int K, int k_chunk) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[64 * TN_LDA];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[64 * TN_LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 128;
+    const int kbeg = blockIdx.z * k_chunk, kend = min(K, kbeg + k_chunk);
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 ra[2], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                    // A tile: 64 k-rows x 64 m (fp32 -> bf16): 8 chunks of 8 per row
+            const int l = tid + e * 256, r = l >> 3, c8 = l & 7;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (k0 + r < kend) {
+                const float* p = A + (long long)(k0 + r) * M + m0 + c8 * 8;
+                const f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 4);
+                v = (uint4){fc_pack2(lo.x, lo.y), fc_pack2(lo.z, lo.w), fc_pack2(hi.x, hi.y), fc_pack2(hi.z, hi.w)};
+            }
+            ra[e] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                    // B tile: 64 k-rows x 128 n: 16 chunks per row
+            const int l = tid + e * 256, r = l >> 4, c8 = l & 15;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (k0 + r < kend) v = *(const uint4*)(B + (long long)(k0 + r) * N + n0 + c8 * 8);
+            rb[e] = v;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { const int l = tid + e * 256; *(uint4*)(As + (l >> 3) * TN_LDA + (l & 7) * 8) = ra[e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int l = tid + e * 256;
+            uint4 v = rb[e];
+            v.x = fc_relu2(v.x); v.y = fc_relu2(v.y); v.z = fc_relu2(v.z); v.w = fc_relu2(v.w);
+            *(uint4*)(Bs + (l >> 4) * TN_LDB + (l & 15) * 8) = v;
+        }
+        __syncthreads();
+        if (k0 + 64 < kend) fetch(k0 + 64);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            int row[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) row[h] = 32 * ks + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq;
+            bf16x8 av[2], bv[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + row[0] * TN_LDA + wm * 32 + a * 16 + 4 * cp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + row[1] * TN_LDA + wm * 32 + a * 16 + 4 * cp));
+                av[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Bs + row[0] * TN_LDB + wn * 64 + b * 16 + 4 * cp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Bs + row[1] * TN_LDB + wn * 64 + b * 16 + 4 * cp));
+                bv[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = MFMA_BF16(av[a], bv[b], acc[a][b]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + a * 16 + kq * 4 + r, n = n0 + wn * 64 + b * 16 + i;
+                ws[((long long)blockIdx.z * M + m) * N + n] = acc[a][b][r];
+            }
+}
+__global__ void fc_tn_reduce_kernel(const float* __restrict__ ws, int split, long long total, float* __restrict__ gW) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+    for (int z = 0; z < split; ++z) s += ws[(long long)z * total + e];
+    gW[e] += s;
+}
+// A: fp32 [K][M], B: bf16 [K][N], gW fp32 [M][N] accumulated; ws: >= split*M*N floats.  M % 64 == 0, N % 128 == 0.
+void launch_fc_tn(const float* A, const unsigned short* B, float* gW, float* ws, size_t ws_floats, int M, int N, int K, hipStream_t st) {
+    if (K <= 0) return;
+    int split = 8;
+    while (split > 1 && ((size_t)split * M * N > ws_floats || K / split < 64)) split >>= 1;
+    const int k_chunk = ((K + split - 1) / split + 63) / 64 * 64;
+    split = (K + k_chunk - 1) / k_chunk;
+    hipLaunchKernelGGL(fc_tn_kernel, dim3(N / 128, M / 64, split), dim3(256), 0, st, A, B, ws, M, N, K, k_chunk);
+    const long long total = (long long)M * N;
+    hipLaunchKernelGGL(fc_tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)ws, split, total, gW);
+}
+
+// embedder.fc: y[n][256] = relu(relu(x)[n][2048] * W^T + b)
+void launch_fc_fwd_bf16(const void* x_bf16, const unsigned short* wp, const float* bias, float* y, int n, hipStream_t st) {
+    FcNtArgs g{};
+    g.A = x_bf16; g.Bp = wp; g.C = y; g.M = n; g.N = 256; g.K = 2048; g.bias = bias; g.mask = nullptr;
+    g.a_f32 = 0; g.relu_a = 1; g.relu_out = 1; g.c_bf16 = 0;
+    launch_fc_nt(g, st);
+}
+// dx[n][2048] (bf16) = (dy[n][256] * W) * (x > 0)
+void launch_fc_dgrad_bf16(const float* dy, const unsigned short* wt, const void* mask_bf16, void* dx_bf16, int n, hipStream_t st) {
+    FcNtArgs g{};
+    g.A = dy; g.Bp = wt; g.C = dx_bf16; g.M = n; g.N = 2048; g.K = 256; g.bias = nullptr; g.mask = (const unsigned short*)mask_bf16;
+    g.a_f32 = 1; g.relu_a = 0; g.relu_out = 0; g.c_bf16 = 1;
+    launch_fc_nt(g, st);
+}
