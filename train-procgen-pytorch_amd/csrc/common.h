@@ -24,6 +24,7 @@ struct ConvArgs {
     int            n;         // images
     int            relu_in;   // apply max(x,0) while staging the input tile
     int            bf16;      // activations (in/res/mask/out) are bf16 in HBM
+    const unsigned short* wbank;   // bf16 mode: pre-packed filter bank in the kernel's LDS layout (conv_bf16.hip), or null
 };
 
 struct WgradArgs {
@@ -133,3 +134,12 @@ void launch_fc_pack(const float* w, unsigned short* wp, unsigned short* wt, int 
 void launch_fc_fwd_bf16(const void* x_bf16, const unsigned short* wp, const float* bias, float* y, int n, hipStream_t st);
 void launch_fc_dgrad_bf16(const float* dy, const unsigned short* wt, const void* mask_bf16, void* dx_bf16, int n, hipStream_t st);
 void launch_fc_tn(const float* A, const unsigned short* B, float* gW, float* ws, size_t ws_floats, int M, int N, int K, hipStream_t st);
+
+// fused residual block forward, bf16 mode (resblock_bf16.hip); s = ConvShape of the block's convs
+void launch_resblock_bf16(ConvShape s, const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* a_out,
+                          void* y_out, int n, const unsigned short* bank1, const unsigned short* bank2, hipStream_t st);
+// pre-packed bf16 filter banks: [rows][WS] with WS = NK*32+16, K laid out tap-major (conv_bf16.hip); rows = output
+// channels of the pass (dgrad: transposed + tap-mirrored view).  One descriptor per bank, device-resident.
+struct BankDesc { long long w_off, out_off; int rows, cin_pass, co_f, ci_f, transw, ws, nk; };
+int  bank_ws(int cin_pass);                 // elements per bank row
+void launch_pack_banks(const float* params, unsigned short* banks, const BankDesc* d_desc, int n_desc, hipStream_t st);

@@ -91,7 +91,12 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a) {
     const unsigned short* g_res = (const unsigned short*)a.res;
     unsigned short* g_out = (unsigned short*)a.out;
 
-    // filter bank -> LDS [co][tap-major K][ci] in bf16 (dgrad: co<->ci swapped, taps mirrored); K padded with zeros
+    // filter bank -> LDS [co][tap-major K][ci] in bf16 (dgrad: co<->ci swapped, taps mirrored); K padded with zeros.
+    // Normally a straight 16-byte copy of the image pack_banks_kernel refreshed after the last optimizer step (the
+    // per-element fp32 gather + convert below costs ~5 us per launch, which dominated the n = n_envs rollout launches).
+    if (a.wbank) {
+        for (int e = tid; e < C::COUT * C::WS / 8; e += 256) ((uint4*)s_w)[e] = ((const uint4*)a.wbank)[e];
+    } else
     for (int e = tid; e < C::COUT * C::WS; e += 256) {
         const int j = e / C::WS, k = e % C::WS;
         float v = 0.f;
@@ -210,6 +215,24 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a) {
                 }
             }
     }
+}
+
+// ------------------------------------------------------------------------------------------ filter-bank packing
+int bank_ws(int cin_pass) { return (cin_pass == 32 ? 9 : 5) * 32 + 16; }
+__global__ void pack_banks_kernel(const float* __restrict__ params, unsigned short* __restrict__ banks, const BankDesc* __restrict__ desc) {
+    const BankDesc d = desc[blockIdx.y];
+    const float* w = params + d.w_off;                    // forward layout [co_f][9][ci_f]
+    unsigned short* out = banks + d.out_off;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < d.rows * d.ws; e += gridDim.x * blockDim.x) {
+        const int j = e / d.ws, k = e % d.ws, tap = k / d.cin_pass, ci = k % d.cin_pass;
+        float v = 0.f;
+        if (k < d.nk * 32 && tap < 9) v = d.transw ? w[(ci * 9 + (8 - tap)) * d.ci_f + j] : w[(j * 9 + tap) * d.ci_f + ci];
+        out[e] = f2bf(v);
+    }
+}
+void launch_pack_banks(const float* params, unsigned short* banks, const BankDesc* d_desc, int n_desc, hipStream_t st) {
+    if (n_desc <= 0) return;
+    hipLaunchKernelGGL(pack_banks_kernel, dim3(8, n_desc), dim3(256), 0, st, params, banks, d_desc);
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient (bf16)

@@ -35,17 +35,18 @@ struct TensorDesc {
     int kind, co, ci;
 };
 
-struct ConvLayer { ConvShape shape; int64_t w_off, b_off; int cin, cout, hw; };
+struct ConvLayer { ConvShape shape; int64_t w_off, b_off; int cin, cout, hw; long long bank_f, bank_d; };   // bank offsets (bf16 mode) or -1
 struct Block { float *C, *P0, *A1, *P1, *A2, *P2; uint8_t* PI; int cin, cout, hin; };   // activation buffers hold fp32 or bf16 (ctx.bf)
 struct Linear { int64_t w_off, b_off; int in, out; };
 
 // ---- live kernel timing (bench.py roofline leg)
-enum ProfClass { PC_CONV_FWD = 0, PC_CONV_DGRAD = 5, PC_CONV_WGRAD = 10, PC_POOL_FWD = 15, PC_POOL_BWD, PC_GEMM, PC_SLAB_REDUCE, PC_COUNT };
+enum ProfClass { PC_CONV_FWD = 0, PC_CONV_DGRAD = 5, PC_CONV_WGRAD = 10, PC_POOL_FWD = 15, PC_POOL_BWD, PC_GEMM, PC_SLAB_REDUCE, PC_RESBLOCK, PC_COUNT = PC_RESBLOCK + 5 };
 static const char* kProfNames[PC_COUNT] = {
     "conv_fwd_3_16_64", "conv_fwd_16_16_32", "conv_fwd_16_32_32", "conv_fwd_32_32_16", "conv_fwd_32_32_8",
     "conv_dgrad_3_16_64(unused)", "conv_dgrad_16_16_32", "conv_dgrad_16_32_32", "conv_dgrad_32_32_16", "conv_dgrad_32_32_8",
     "conv_wgrad_3_16_64", "conv_wgrad_16_16_32", "conv_wgrad_16_32_32", "conv_wgrad_32_32_16", "conv_wgrad_32_32_8",
-    "maxpool_fwd", "maxpool_bwd", "gemm", "slab_reduce"};
+    "maxpool_fwd", "maxpool_bwd", "gemm", "slab_reduce",
+    "resblock_fwd_(unused)", "resblock_fwd_16_16_32", "resblock_fwd_(unused)", "resblock_fwd_32_32_16", "resblock_fwd_32_32_8"};
 struct ProfPending { hipEvent_t a, b; int cls, phase; long long units; double bytes, flops; };
 struct Profiler {
     bool on = false;
@@ -95,6 +96,7 @@ struct mi_ctx {
     float *loss_partial, *loss_stats, *loss_log; int log_count, log_cap;
     double* sumsq; float* gnorm;
     float* d_u; float* d_lp;
+    unsigned short* banks; BankDesc* d_bank_desc; int n_banks;   // bf16 mode: pre-packed conv filter banks
     unsigned short *fc_wp, *fc_wt;            // bf16 mode: packed fc.weight images ([256][2048] and [2048][256])
     bool fc_packed_valid;
     float *d_pack, *h_pack, *h_rd, *d_rd;     // packed rollout read-back {act,logp,value} x E ; packed {rew,done} upload
@@ -314,6 +316,23 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->multirank = 0; c->pending_n = -1;
     c->fc_wp = c->fc_wt = nullptr; c->fc_packed_valid = false;
     if (c->bf) { HIPC(dalloc(&c->fc_wp, (size_t)256 * 2048)); HIPC(dalloc(&c->fc_wt, (size_t)256 * 2048)); }
+    c->banks = nullptr; c->d_bank_desc = nullptr; c->n_banks = 0;
+    for (auto& L : c->convs) { L.bank_f = -1; L.bank_d = -1; }
+    if (c->bf) {
+        std::vector<BankDesc> desc;
+        long long off = 0;
+        for (auto& L : c->convs) {
+            if (L.cin == 3) continue;                                   // block1.conv stays on the fp32-MFMA kernel
+            BankDesc f{L.w_off, off, L.cout, L.cin, L.cout, L.cin, 0, bank_ws(L.cin), L.cin == 32 ? 9 : 5};
+            L.bank_f = off; off += (long long)f.rows * f.ws; desc.push_back(f);
+            BankDesc d{L.w_off, off, L.cin, L.cout, L.cout, L.cin, 1, bank_ws(L.cout), L.cout == 32 ? 9 : 5};   // dgrad pass: cin_pass = forward cout
+            L.bank_d = off; off += (long long)d.rows * d.ws; desc.push_back(d);
+        }
+        c->n_banks = (int)desc.size();
+        HIPC(dalloc(&c->banks, (size_t)off));
+        HIPC(hipMalloc((void**)&c->d_bank_desc, desc.size() * sizeof(BankDesc)));
+        HIPC(hipMemcpy(c->d_bank_desc, desc.data(), desc.size() * sizeof(BankDesc), hipMemcpyHostToDevice));
+    }
     c->gru_on = false; c->gru_wih = c->gru_whh = c->gru_bih = c->gru_bhh = c->h_state = c->h_masked = c->gru_gi = c->gru_gh = c->d_done = nullptr;
     HIPC(hipDeviceSynchronize());
     *out = c;
@@ -337,6 +356,7 @@ int mi_destroy(mi_ctx* c) {
     if (c->stage_frames) hipFree(c->stage_frames);
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
+    if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc);
     hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
@@ -517,6 +537,7 @@ static void conv_fwd(mi_ctx* c, const ConvLayer& L, const void* in, const InputS
     a.in = src ? src->base : in; a.idx = src ? src->idx : nullptr; a.in_base = src ? src->first : 0;
     a.w = c->params + L.w_off; a.bias = c->params + L.b_off; a.res = res; a.mask = nullptr; a.out = out;
     a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
+    a.wbank = (c->bf && L.bank_f >= 0) ? c->banks + L.bank_f : nullptr;
     const double px = (double)n * L.hw * L.hw, es = c->es;
     ProfScope ps(c, PC_CONV_FWD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : es * L.cin) + es * L.cout * (res ? 2 : 1)), px * 18.0 * L.cin * L.cout);
     launch_conv_fwd(L.shape, a, c->stream);
@@ -525,6 +546,7 @@ static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const f
     ConvArgs a{};
     a.in = dout; a.w = c->params + L.w_off; a.bias = nullptr; a.res = res; a.mask = mask; a.out = din;
     a.lut = c->lut; a.n = n; a.relu_in = 0; a.bf16 = c->bf;
+    a.wbank = (c->bf && L.bank_d >= 0) ? c->banks + L.bank_d : nullptr;
     const double px = (double)n * L.hw * L.hw;
     ProfScope ps(c, PC_CONV_DGRAD + (int)L.shape, n, px * c->es * (L.cout + L.cin * (1 + (mask ? 1 : 0) + (res ? 1 : 0))), px * 18.0 * L.cin * L.cout);
     launch_conv_dgrad(L.shape, a, c->stream);
@@ -586,10 +608,15 @@ static void net_gru(mi_ctx* c, int n) {
 }
 
 static void fc_refresh(mi_ctx* c) {
-    if (c->bf && !c->fc_packed_valid) { launch_fc_pack(c->params + c->fc.w_off, c->fc_wp, c->fc_wt, 256, 2048, c->stream); c->fc_packed_valid = true; }
+    if (c->bf && !c->fc_packed_valid) {
+        launch_fc_pack(c->params + c->fc.w_off, c->fc_wp, c->fc_wt, 256, 2048, c->stream);
+        launch_pack_banks(c->params, c->banks, c->d_bank_desc, c->n_banks, c->stream);
+        c->fc_packed_valid = true;
+    }
 }
 
-static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = false, bool with_heads = true) {
+static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = false, bool with_heads = true, bool train = false) {
+    fc_refresh(c);          // bf16 mode: packed fc / conv filter images follow the parameters
     if (c->cfg.arch == MI_ARCH_IMPALA) {
         const float* prev = nullptr;
         for (int b = 0; b < 3; ++b) {
@@ -599,10 +626,21 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
             else conv_fwd(c, L[0], prev, nullptr, 0, nullptr, k.C, n);
             { ProfScope ps(c, PC_POOL_FWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
               if (c->bf) launch_maxpool_fwd_bf16(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); else launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); }
-            conv_fwd(c, L[1], k.P0, nullptr, 1, nullptr, k.A1, n);
-            conv_fwd(c, L[2], k.A1, nullptr, 1, k.P0, k.P1, n);
-            conv_fwd(c, L[3], k.P1, nullptr, 1, nullptr, k.A2, n);
-            conv_fwd(c, L[4], k.A2, nullptr, 1, k.P1, k.P2, n);
+            if (c->bf) {                     // fused residual blocks; the intermediate is written only when a backward pass follows
+                const double px = (double)n * L[1].hw * L[1].hw, ch = L[1].cout;
+                for (int r = 0; r < 2; ++r) {
+                    const ConvLayer &l1 = L[1 + 2 * r], &l2 = L[2 + 2 * r];
+                    float* x = r ? k.P1 : k.P0; float* a_out = train ? (r ? k.A2 : k.A1) : nullptr; float* y = r ? k.P2 : k.P1;
+                    ProfScope ps(c, PC_RESBLOCK + (int)l1.shape, n, px * ch * 2.0 * (train ? 3 : 2), 2.0 * px * 18.0 * ch * ch);
+                    launch_resblock_bf16(l1.shape, x, c->params + l1.w_off, c->params + l1.b_off, c->params + l2.w_off, c->params + l2.b_off, a_out, y, n,
+                                         c->banks + l1.bank_f, c->banks + l2.bank_f, c->stream);
+                }
+            } else {
+                conv_fwd(c, L[1], k.P0, nullptr, 1, nullptr, k.A1, n);
+                conv_fwd(c, L[2], k.A1, nullptr, 1, k.P0, k.P1, n);
+                conv_fwd(c, L[3], k.P1, nullptr, 1, nullptr, k.A2, n);
+                conv_fwd(c, L[4], k.A2, nullptr, 1, k.P1, k.P2, n);
+            }
             prev = k.P2;
         }
         if (c->bf && n >= 1024) {               // update-sized batches: bf16 matrix cores (fc_bf16.hip)
@@ -881,7 +919,7 @@ int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, con
     }
     InputSrc src = minibatch_src(c);
     c->prof.phase = 1;
-    net_forward(c, src, n);
+    net_forward(c, src, n, false, true, true);
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
     if (impala) launch_fs_metric(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_val, c->stream);
     LossArgs a{};

@@ -692,55 +692,58 @@ __device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigne
 }
 // Rollout head, fused: policy/value heads (common/policy.py:74-80) + log-softmax + sample + log_prob
 // (agents/ppo.py:77-79) for one env per wave; results also packed [n][3] = {act, logp, value} for ONE read-back.
+// 16 envs per workgroup: the 16 feature rows go through LDS, thread (env, output) owns one dot product, then one
+// thread per env normalises and samples.
 __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restrict__ feat, const float* __restrict__ Wh,
                                                            const float* __restrict__ bh, int n, int H, int A, const float* u,
                                                            unsigned long long seed, unsigned long long ctr, int32_t* act,
                                                            float* logp, float* value, float* pack, float* hout,
                                                            const float* rd, float* rew_dst, float* done_dst) {
-    const int lane = threadIdx.x & 63, e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= n) return;                                   // whole waves exit together
-    if (rd && lane == 1) { rew_dst[e] = rd[e]; done_dst[e] = rd[n + e]; }   // previous step's reward / done into the (T,E) arrays
-    float z[MAXA + 1];                                   // statically indexed everywhere (a runtime-indexed array would live in scratch)
-#pragma unroll
-    for (int o = 0; o <= MAXA; ++o) z[o] = 0.f;
-    for (int k = lane; k < H; k += 64) {
-        const float f = feat[(long long)e * H + k];
-#pragma unroll
-        for (int o = 0; o <= MAXA; ++o)
-            if (o <= A) z[o] += f * Wh[(long long)o * H + k];
+    __shared__ __attribute__((aligned(16))) float s_f[16 * 260];
+    __shared__ float s_z[16 * 17];
+    const int tid = threadIdx.x, e0 = blockIdx.x * 16;
+    for (int k = tid; k < 16 * H; k += 256) {
+        const int el = k / H, kk = k % H;
+        s_f[el * 260 + kk] = (e0 + el < n) ? feat[(long long)(e0 + el) * H + kk] : 0.f;
     }
-#pragma unroll
-    for (int o = 0; o <= MAXA; ++o) {
-        float v = z[o];
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
-        z[o] = (o <= A) ? v + bh[o] : 0.f;
+    __syncthreads();
+    const int el = tid >> 4, o = tid & 15;
+    for (int oo = o; oo <= A; oo += 16) {                 // A+1 <= 17 outputs: output 16 (if any) is taken by o == 0
+        const float* w = Wh + (long long)oo * H;
+        float acc = 0.f;
+        int k = 0;
+        for (; k + 4 <= H; k += 4) {                       // H is 256 (IMPALA) or 64 (MLP): 16-byte aligned rows
+            const f32x4 f = *(const f32x4*)(s_f + el * 260 + k), ww = *(const f32x4*)(w + k);
+            acc += f.x * ww.x + f.y * ww.y + f.z * ww.z + f.w * ww.w;
+        }
+        for (; k < H; ++k) acc += s_f[el * 260 + k] * w[k];
+        s_z[el * 17 + oo] = acc + bh[oo];
     }
-    if (lane != 0) return;
-    float lp[MAXA], p[MAXA];
+    __syncthreads();
+    if (tid >= 16) return;
+    const int e = e0 + tid;
+    if (e >= n) return;
+    if (rd) { rew_dst[e] = rd[e]; done_dst[e] = rd[n + e]; }     // previous step's reward / done into the (T,E) arrays
+    float z[MAXA], lp[MAXA], p[MAXA];
+    for (int k = 0; k < A; ++k) z[k] = s_z[tid * 17 + k];
     log_softmax_twice(z, A, lp, p);
     const float uu = u ? u[e] : philox_uniform(seed, ctr + e);
     float cdf = 0.f;
     int a_sel = 0;
     for (int k = 0; k < A; ++k) { cdf += expf(lp[k]); if (cdf <= uu) a_sel = k + 1; }
     if (a_sel > A - 1) a_sel = A - 1;
+    const float val = s_z[tid * 17 + A];
     if (act) act[e] = a_sel;
     if (logp) logp[e] = lp[a_sel];
-    float val = 0.f;
-#pragma unroll
-    for (int o = 0; o <= MAXA; ++o) if (o == A) val = z[o];
     if (value) value[e] = val;
     if (pack) { pack[e * 3] = (float)a_sel; pack[e * 3 + 1] = lp[a_sel]; pack[e * 3 + 2] = val; }
-    if (hout) {
-#pragma unroll
-        for (int o = 0; o <= MAXA; ++o) if (o <= A) hout[(long long)e * (A + 1) + o] = z[o];
-    }
+    if (hout) for (int k = 0; k <= A; ++k) hout[(long long)e * (A + 1) + k] = s_z[tid * 17 + k];
 }
 void launch_heads_sample(const float* feat, const float* Wh, const float* bh, int n, int H, int A, const float* u,
                          unsigned long long seed, unsigned long long ctr, int32_t* act, float* logp, float* value, float* pack,
                          float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(heads_sample_kernel, dim3((n + 3) / 4), dim3(256), 0, st, feat, Wh, bh, n, H, A, u, seed, ctr, act, logp, value, pack, hout,
+    hipLaunchKernelGGL(heads_sample_kernel, dim3((n + 15) / 16), dim3(256), 0, st, feat, Wh, bh, n, H, A, u, seed, ctr, act, logp, value, pack, hout,
                        rd, rew_dst, done_dst);
 }
 void launch_sample(const float* hout, int n, int A, const float* u, unsigned long long seed, unsigned long long ctr,
