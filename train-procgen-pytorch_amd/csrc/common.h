@@ -25,6 +25,7 @@ struct ConvArgs {
     int            relu_in;   // apply max(x,0) while staging the input tile
     int            bf16;      // activations (in/res/mask/out) are bf16 in HBM
     const unsigned short* wbank;   // bf16 mode: pre-packed filter bank in the kernel's LDS layout (conv_bf16.hip), or null
+    const unsigned short* lut16;   // bf16 mode: 256-entry uint8 -> bf16 table (block1.conv)
 };
 
 struct WgradArgs {
@@ -37,6 +38,7 @@ struct WgradArgs {
     int            n;
     int            relu_in;
     int            bf16;      // in (unless uint8 frames) and dout are bf16 in HBM
+    const unsigned short* lut16;   // bf16 mode: uint8 -> bf16 table (block1.conv)
 };
 
 enum ConvShape {              // (CIN, COUT, HW) of the FORWARD conv
@@ -56,6 +58,8 @@ void launch_conv_wgrad(ConvShape s, const WgradArgs& a, hipStream_t st);
 void conv_shape_dims(ConvShape s, int* cin, int* cout, int* hw);
 void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st);     // conv_bf16.hip (bf16 MFMA)
 void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st);
+void launch_conv1_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, hipStream_t st);
+void launch_conv1_wgrad_bf16(const WgradArgs& a, const unsigned short* lut16, hipStream_t st);
 int  wgrad_grid_bf16(ConvShape s, int n);                                  // -1: shape handled by conv.hip
 void launch_conv_wgrad_bf16(ConvShape s, const WgradArgs& a, hipStream_t st);
 int  wgrad_grid_for(ConvShape s, int n, int bf16);                          // slabs a wgrad launch writes

@@ -546,7 +546,8 @@ void conv_shape_dims(ConvShape s, int* cin, int* cout, int* hw) {
 
 void launch_conv_fwd(ConvShape s, const ConvArgs& a, hipStream_t st) {
     if (a.bf16) {
-        if (s == CS_3_16_64) launch_fwd_t<FB_3_16_64>(a, st); else launch_conv_fwd_bf16(s, a, st);
+        if (s == CS_3_16_64) launch_conv1_fwd_bf16(a, a.lut16, st);       // lut16 is always set in bf16 mode
+        else launch_conv_fwd_bf16(s, a, st);
         return;
     }
     switch (s) {
@@ -584,12 +585,13 @@ int wgrad_grid(ConvShape s, int n) {
 }
 
 int wgrad_grid_for(ConvShape s, int n, int bf16) {
-    if (bf16) { const int g = wgrad_grid_bf16(s, n); if (g >= 0) return g; return wg_grid_t<WB_3_16_64>(n); }
+    if (bf16) { const int g = wgrad_grid_bf16(s, n); if (g >= 0) return g; return wg_grid_t<WB_3_16_64>(n); }   // (conv1 without lut16: see launch)
     return wgrad_grid(s, n);
 }
 
 void launch_conv_wgrad(ConvShape s, const WgradArgs& a, hipStream_t st) {
     if (a.bf16) {
+        if (s == CS_3_16_64) { launch_conv1_wgrad_bf16(a, a.lut16, st); return; }
         if (wgrad_grid_bf16(s, a.n) >= 0) { launch_conv_wgrad_bf16(s, a, st); return; }
         switch (s) {
             case CS_3_16_64:  launch_wg_t<WB_3_16_64>(a, st); break;

@@ -10,6 +10,7 @@
 // kq&1 the 8-channel half), the 10th "tap" being a zero column of the filter bank.
 #include "common.h"
 
+static int c1_grid(int n);          // persistent grid of the block1.conv weight-gradient kernel (defined with it)
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
@@ -422,7 +423,8 @@ int wgrad_grid_bf16(ConvShape s, int n) {
         case CS_16_32_32: return wb_grid<WT_16_32_32>(n);
         case CS_32_32_16: return wb_grid<WT_32_32_16>(n);
         case CS_32_32_8:  return wb_grid<WT_32_32_8>(n);
-        default: return -1;      // block1.conv: fp32-arithmetic kernel of conv.hip
+        case CS_3_16_64:  return c1_grid(n);
+        default: return -1;
     }
 }
 void launch_conv_wgrad_bf16(ConvShape s, const WgradArgs& a, hipStream_t st) {
@@ -433,6 +435,206 @@ void launch_conv_wgrad_bf16(ConvShape s, const WgradArgs& a, hipStream_t st) {
         case CS_32_32_8:  launch_wb_t<WT_32_32_8>(a, st); break;
         default: break;
     }
+}
+
+// ------------------------------------------------------------------------------------------ block1.conv (3 -> 16 @ 64x64, uint8 frames in)
+// Forward: the haloed frame tile is staged as bf16 [pixel][r,g,b,0] (8 bytes per pixel, uint8 -> bf16 through a
+// 256-entry table); K = 9 taps x 4 = 36 -> two K=32 MFMAs: the first covers taps 0..7 (lane quarter kq owns taps
+// 2kq, 2kq+1: two 8-byte LDS reads), the second tap 8 (+ zero columns).  Weight gradient: M = 16 output channels,
+// N = (tap, ci) = 27 -> 32 columns, K = pixels; the B operand needs the 27 values of a pixel contiguous, so an
+// im2col image [pixel][32] is built in LDS from the staged tile (9 8-byte reads + 4 16-byte writes per pixel) and
+// both operands come through ds_read_b64_tr_b16.
+template <int TH_>
+struct C1T {
+    static constexpr int HW = 64, TH = TH_, TW = 64, PH = TH + 2, PW = 66, NPIX = PH * PW, NT = TH * TW;
+    static constexpr int ROW_DW = HW * 3 / 4, NLD = (PH * ROW_DW + 255) / 256;       // frame rows as dwords
+    static constexpr int TPI = HW / TH;
+};
+using C1 = C1T<8>;          // forward tile
+using C1W = C1T<4>;         // weight-gradient tile (smaller LDS footprint -> 4 workgroups per CU)
+template <class C1>
+__device__ __forceinline__ void c1_load(uint32_t (&r)[C1::NLD], const uint8_t* frames, const int32_t* idx, long long in_base, int img, int ty0) {
+#pragma unroll
+    for (int k = 0; k < C1::NLD; ++k) {
+        const int e = threadIdx.x + k * 256;
+        uint32_t v = 0u;
+        if (e < C1::PH * C1::ROW_DW) {
+            const int row = e / C1::ROW_DW, dw = e % C1::ROW_DW, gy = ty0 + row - 1;
+            if (gy >= 0 && gy < C1::HW) {
+                const long long frame = idx ? (long long)idx[img] : in_base + img;
+                v = *(const uint32_t*)(frames + frame * (C1::HW * C1::HW * 3) + gy * (C1::HW * 3) + dw * 4);
+            }
+        }
+        r[k] = v;
+    }
+}
+template <class C1>
+__device__ __forceinline__ void c1_store(const uint32_t (&r)[C1::NLD], unsigned short* s_in, const unsigned short* lut16) {
+#pragma unroll
+    for (int k = 0; k < C1::NLD; ++k) {
+        const int e = threadIdx.x + k * 256;
+        if (e < C1::PH * C1::ROW_DW) {
+            const int row = e / C1::ROW_DW, dw = e % C1::ROW_DW;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int byte = dw * 4 + b, px = byte / 3, ch = byte % 3;
+                s_in[(row * C1::PW + 1 + px) * 4 + ch] = lut16[(r[k] >> (8 * b)) & 0xffu];      // lut16[0] == 0: padded rows
+            }
+        }
+    }
+}
+
+constexpr int C1_WS = 80;          // bf16 elements per output channel of the 64-column filter bank (conflict-free rows)
+__global__ __launch_bounds__(256) void conv1_fwd_bf16_kernel(ConvArgs a, const unsigned short* lut16) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_in[C1::NPIX * 4];
+    __shared__ __attribute__((aligned(16))) unsigned short s_w[16 * C1_WS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    unsigned short* g_out = (unsigned short*)a.out;
+    for (int e = tid; e < 16 * C1_WS; e += 256) {        // K index k = tap*4 + ci (ci == 3 and k >= 36 are zero columns)
+        const int j = e / C1_WS, k = e % C1_WS, tap = k / 4, ci = k % 4;
+        s_w[e] = f2bf((k < 36 && ci < 3) ? a.w[(j * 9 + tap) * 3 + ci] : 0.f);
+    }
+    for (int e = tid; e < C1::NPIX * 4; e += 256) s_in[e] = 0;
+    const float bias = a.bias ? a.bias[i] : 0.f;
+    int off0, off1;                                        // this lane's two taps of the first MFMA
+    { const int t0 = 2 * kq, t1 = 2 * kq + 1; off0 = ((t0 / 3) * C1::PW + t0 % 3) * 4; off1 = ((t1 / 3) * C1::PW + t1 % 3) * 4; }
+    constexpr int off8 = (2 * C1::PW + 2) * 4;
+    const int nwork = a.n * C1::TPI;
+    uint32_t regs[C1::NLD];
+    if ((int)blockIdx.x < nwork) c1_load<C1>(regs, (const uint8_t*)a.in, a.idx, a.in_base, blockIdx.x / C1::TPI, (blockIdx.x % C1::TPI) * C1::TH);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int img = work / C1::TPI, ty0 = (work % C1::TPI) * C1::TH;
+        __syncthreads();
+        c1_store<C1>(regs, s_in, lut16);
+        __syncthreads();
+        if (work + (int)gridDim.x < nwork) { const int w2 = work + gridDim.x; c1_load<C1>(regs, (const uint8_t*)a.in, a.idx, a.in_base, w2 / C1::TPI, (w2 % C1::TPI) * C1::TH); }
+        const bf16x8 bw1 = *(const bf16x8*)(s_w + i * C1_WS + kq * 8);
+        const bf16x8 bw2 = *(const bf16x8*)(s_w + i * C1_WS + 32 + kq * 8);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int pl = (wave * 8 + mt) * 16 + i, y = pl / C1::TW, x = pl % C1::TW;
+            const unsigned short* p = s_in + (y * C1::PW + x) * 4;
+            const uint2 lo = *(const uint2*)(p + off0), hi = *(const uint2*)(p + off1), t8 = *(const uint2*)(p + off8);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, (uint4){lo.x, lo.y, hi.x, hi.y});
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, (uint4){t8.x, t8.y, 0u, 0u});
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = MFMA_BF16(a1, bw1, acc);
+            acc = MFMA_BF16(a2, bw2, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int po = (wave * 8 + mt) * 16 + kq * 4 + r;
+                g_out[(((long long)img * C1::HW + ty0 + po / C1::TW) * C1::HW + po % C1::TW) * 16 + i] = f2bf(acc[r] + bias);
+            }
+        }
+    }
+}
+
+constexpr int C1_SI = 48;          // im2col row stride (bf16 elements): 16 x odd -> conflict-free transpose reads
+__global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, const unsigned short* lut16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_in = smem_h;                                   // [660][4]
+    unsigned short* s_col = smem_h + ((C1W::NPIX * 4 + 7) / 8) * 8;   // [512][48] (27 real columns)
+    unsigned short* s_do = s_col + C1W::NT * C1_SI;                   // [512][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    const unsigned short* g_do = (const unsigned short*)a.dout;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float bsum = 0.f;
+    const int bc = tid & 15, bg = tid >> 4;
+    for (int e = tid; e < C1W::NPIX * 4; e += 256) s_in[e] = 0;
+    const int nwork = a.n * C1W::TPI;
+    uint32_t regs[C1W::NLD];
+    constexpr int NDO = C1W::NT * 2 / 256;                            // NT px x 2 chunks of 8 channels
+    uint4 rdo[NDO];
+    auto load_do = [&](int img, int ty0) {
+#pragma unroll
+        for (int k = 0; k < NDO; ++k) {
+            const int e = tid + k * 256, pl = e >> 1, c8 = e & 1;
+            rdo[k] = *(const uint4*)(g_do + (((long long)img * C1W::HW + ty0 + pl / C1W::TW) * C1W::HW + pl % C1W::TW) * 16 + c8 * 8);
+        }
+    };
+    if ((int)blockIdx.x < nwork) {
+        const int img = blockIdx.x / C1W::TPI, ty0 = (blockIdx.x % C1W::TPI) * C1W::TH;
+        c1_load<C1W>(regs, (const uint8_t*)a.in, a.idx, a.in_base, img, ty0); load_do(img, ty0);
+    }
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        __syncthreads();
+        c1_store<C1W>(regs, s_in, lut16);
+#pragma unroll
+        for (int k = 0; k < NDO; ++k) { const int e = tid + k * 256; *(uint4*)(s_do + (e >> 1) * 16 + (e & 1) * 8) = rdo[k]; }
+        __syncthreads();
+        if (work + (int)gridDim.x < nwork) {
+            const int w2 = work + gridDim.x, img = w2 / C1W::TPI, ty0 = (w2 % C1W::TPI) * C1W::TH;
+            c1_load<C1W>(regs, (const uint8_t*)a.in, a.idx, a.in_base, img, ty0); load_do(img, ty0);
+        }
+        // im2col: pixel p -> its 27 (tap, ci) values, contiguous (columns 27..31 zero)
+#pragma unroll
+        for (int h = 0; h < C1W::NT / 256; ++h) {
+            const int pl = tid + h * 256, y = pl / C1W::TW, x = pl % C1W::TW;
+            unsigned short v[32];
+#pragma unroll
+            for (int k = 27; k < 32; ++k) v[k] = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const uint2 t = *(const uint2*)(s_in + ((y + tap / 3) * C1W::PW + x + tap % 3) * 4);
+                v[tap * 3] = (unsigned short)(t.x & 0xffffu); v[tap * 3 + 1] = (unsigned short)(t.x >> 16); v[tap * 3 + 2] = (unsigned short)(t.y & 0xffffu);
+            }
+            uint4* d = (uint4*)(s_col + pl * C1_SI);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                d[k] = (uint4){(unsigned)v[8 * k] | ((unsigned)v[8 * k + 1] << 16), (unsigned)v[8 * k + 2] | ((unsigned)v[8 * k + 3] << 16),
+                               (unsigned)v[8 * k + 4] | ((unsigned)v[8 * k + 5] << 16), (unsigned)v[8 * k + 6] | ((unsigned)v[8 * k + 7] << 16)};
+        }
+        __syncthreads();
+        for (int t = wave; t < C1W::NT / 32; t += 4) {
+            int row[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) row[h] = 32 * t + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq;
+            const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + row[0] * 16 + 4 * cp));
+            const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + row[1] * 16 + 4 * cp));
+            const bf16x8 av = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_col + row[0] * C1_SI + ib * 16 + 4 * cp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_col + row[1] * C1_SI + ib * 16 + 4 * cp));
+                acc[ib] = MFMA_BF16(av, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), acc[ib]);
+            }
+        }
+        for (int p = bg; p < C1W::NT; p += 16) bsum += bf2f(s_do[p * 16 + bc]);
+    }
+    __syncthreads();
+    float* red = (float*)smem_h;                 // 432 weights + 256 bias partials
+    float* redb = red + 432;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jj = ib * 16 + i;
+                    if (jj < 27) { const int o = (kq * 4 + r) * 27 + jj; red[o] = (w == 0) ? acc[ib][r] : red[o] + acc[ib][r]; }
+                }
+        }
+        __syncthreads();
+    }
+    redb[tid] = bsum;
+    __syncthreads();
+    float* slab = a.partial + (long long)blockIdx.x * 448;
+    for (int e = tid; e < 432; e += 256) slab[e] = red[e];
+    if (tid < 16) { float sum = 0.f; for (int g = 0; g < 16; ++g) sum += redb[g * 16 + tid]; slab[432 + tid] = sum; }
+}
+constexpr size_t C1_WG_LDS = (size_t)(((C1W::NPIX * 4 + 7) / 8) * 8 + C1W::NT * C1_SI + C1W::NT * 16) * 2;
+static int c1_grid(int n) { const int w = n * C1W::TPI; return w > 1024 ? 1024 : w; }
+void launch_conv1_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, hipStream_t st) {
+    const int w = a.n * C1::TPI, grid = w > 1024 ? 1024 : w;
+    if (grid < 1) return;
+    hipLaunchKernelGGL(conv1_fwd_bf16_kernel, dim3(grid), dim3(256), 0, st, a, lut16);
+}
+void launch_conv1_wgrad_bf16(const WgradArgs& a, const unsigned short* lut16, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)conv1_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_WG_LDS); attr = true; }
+    const int grid = c1_grid(a.n);
+    if (grid < 1) return;
+    hipLaunchKernelGGL(conv1_wgrad_bf16_kernel, dim3(grid), dim3(256), C1_WG_LDS, st, a, lut16);
 }
 
 // ------------------------------------------------------------------------------------------ launchers

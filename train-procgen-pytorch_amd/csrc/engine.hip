@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+static std::vector<uint16_t> host_to_bf16(const float* x, size_t n);
 static thread_local std::string g_err;
 const char* mi_last_error(void) { return g_err.c_str(); }
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -91,6 +92,7 @@ struct mi_ctx {
     float* slabs; size_t slab_floats;
     float *gemm_ws, *col_ws, *fs_scratch, *fs_val;
     float* lut;
+    unsigned short* lut16;     // uint8 -> bf16(k/255) table (bf16 mode, block1.conv)
     uint8_t* stage_frames; float* stage_obs;
     int32_t* d_idx;
     float *loss_partial, *loss_stats, *loss_log; int log_count, log_cap;
@@ -220,6 +222,9 @@ template <typename T>
 static hipError_t dalloc(T** p, size_t count) {
     hipError_t e = hipMalloc((void**)p, count * sizeof(T) + 256);
     if (e == hipSuccess) e = hipMemset(*p, 0, count * sizeof(T) + 256);
+    // hipMemset is asynchronous on the NULL stream and the context's stream is non-blocking: without this wait a
+    // kernel launched right after (the op-level test hooks do that) can be overtaken by the zero fill
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     return e;
 }
 
@@ -293,6 +298,12 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         float h[256];
         for (int k = 0; k < 256; ++k) h[k] = (float)((double)k / 255.0);   // ScaledFloatFrame: obs / 255.0 in fp64, then fp32
         HIPC(hipMemcpy(c->lut, h, sizeof(h), hipMemcpyHostToDevice));
+    }
+    HIPC(dalloc(&c->lut16, 256));
+    {
+        float h[256]; for (int k = 0; k < 256; ++k) h[k] = (float)((double)k / 255.0);
+        std::vector<uint16_t> b = host_to_bf16(h, 256);
+        HIPC(hipMemcpy(c->lut16, b.data(), 512, hipMemcpyHostToDevice));
     }
     HIPC(dalloc(&c->d_idx, (size_t)NB));
     HIPC(dalloc(&c->loss_partial, (size_t)(loss_blocks(NB) + 1) * 32));
@@ -538,6 +549,7 @@ static void conv_fwd(mi_ctx* c, const ConvLayer& L, const void* in, const InputS
     a.w = c->params + L.w_off; a.bias = c->params + L.b_off; a.res = res; a.mask = nullptr; a.out = out;
     a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
     a.wbank = (c->bf && L.bank_f >= 0) ? c->banks + L.bank_f : nullptr;
+    a.lut16 = c->bf ? c->lut16 : nullptr;
     const double px = (double)n * L.hw * L.hw, es = c->es;
     ProfScope ps(c, PC_CONV_FWD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : es * L.cin) + es * L.cout * (res ? 2 : 1)), px * 18.0 * L.cin * L.cout);
     launch_conv_fwd(L.shape, a, c->stream);
@@ -555,6 +567,7 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
     WgradArgs a{};
     a.in = src ? src->base : in; a.idx = src ? src->idx : nullptr; a.in_base = src ? src->first : 0;
     a.dout = dout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
+    a.lut16 = c->bf ? c->lut16 : nullptr;
     const int grid = wgrad_grid_for(L.shape, n, c->bf);
     if (grid < 1) return;
     if ((size_t)grid * (size_t)(L.cout * 9 * L.cin + L.cout) > c->slab_floats) { fprintf(stderr, "mi355ppo: wgrad slab workspace too small\n"); abort(); }
@@ -1058,6 +1071,7 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
         ConvArgs a{};
         a.in = (mode == 0) ? din : ddout; a.idx = nullptr; a.in_base = 0; a.w = dw; a.bias = (mode == 0) ? db : nullptr;
         a.res = dres; a.mask = dmask; a.out = dout_buf; a.lut = c->lut; a.n = n; a.relu_in = (mode == 0) ? relu_in : 0; a.bf16 = c->bf;
+        a.lut16 = c->bf ? c->lut16 : nullptr;
         if (mode == 0) launch_conv_fwd(s, a, c->stream); else launch_conv_dgrad(s, a, c->stream);
         HIPC(hipGetLastError());
         HIPC(hipStreamSynchronize(c->stream));
@@ -1068,6 +1082,7 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
         HIPC(dalloc(&g, td.n + cout));
         WgradArgs a{};
         a.in = din; a.idx = nullptr; a.in_base = 0; a.dout = ddout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
+        a.lut16 = c->bf ? c->lut16 : nullptr;
         const int grid = wgrad_grid_for(s, n, c->bf);
         launch_conv_wgrad(s, a, c->stream);
         launch_reduce_slabs(c->slabs, grid, (int)td.n + cout, g, (int)td.n, g + td.n, cout, c->stream);
