@@ -88,6 +88,28 @@ def test_conv_wgrad_bf16_inputs(eng, cin, cout, hw, n):
     assert relerr(gb, dout.sum(dim=(0, 2, 3)).numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("n", [1, 5, 37])
+def test_block1_conv_pool_fused_bf16(eng, n):
+    """block1.conv + MaxPool2d(3,2,1) in one launch (the conv output lives in LDS only), and the weight gradient taken
+    straight from the POOLED gradient + arg-max bytes (pool backward fused into the operand staging).  The unfused
+    kernels are the oracle for the forward (bit-identical: same conv arithmetic, same tie rule); torch autograd on the
+    bf16-rounded conv output for the gradient."""
+    w, b, x_u8, x = _inputs(3, 16, 64, n, 11)
+    conv = eng.op_conv3x3(0, 3, 16, 64, w.numpy(), inp=x_u8, bias=b.numpy())              # unfused conv (bf16 values)
+    pooled = eng.op_conv3x3(3, 3, 16, 64, w.numpy(), inp=x_u8, bias=b.numpy())
+    assert np.array_equal(pooled, eng.op_maxpool(0, conv))
+    c = torch.from_numpy(conv).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = F.max_pool2d(c, kernel_size=3, stride=2, padding=1)
+    assert np.array_equal(pooled, nhwc(y.detach()))
+    dy = r16(torch.randn(y.shape, generator=torch.Generator().manual_seed(12)))
+    y.backward(dy)
+    dc = r16(c.grad)                                                                      # the fused staging rounds the gathered sum to bf16
+    ref_w = torch.nn.grad.conv2d_weight(x, w.shape, dc, padding=1)
+    gw, gb = eng.op_conv3x3(4, 3, 16, 64, w.numpy(), inp=x_u8, bias=b.numpy(), dout=nhwc(dy))
+    assert relerr(gw, ref_w.numpy()) < 1e-4
+    assert relerr(gb, dc.sum(dim=(0, 2, 3)).numpy()) < 1e-4
+
+
 @pytest.mark.parametrize("hw,c", [(64, 16), (32, 32), (16, 32)])
 def test_maxpool_bf16(eng, hw, c):
     g = torch.Generator().manual_seed(hw)

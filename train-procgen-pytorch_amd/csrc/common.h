@@ -39,6 +39,7 @@ struct WgradArgs {
     int            relu_in;
     int            bf16;      // in (unless uint8 frames) and dout are bf16 in HBM
     const unsigned short* lut16;   // bf16 mode: uint8 -> bf16 table (block1.conv)
+    const uint8_t* pool_arg;       // block1.conv, bf16: dout is the POOLED gradient (32x32x16) + these arg-max bytes
 };
 
 enum ConvShape {              // (CIN, COUT, HW) of the FORWARD conv
@@ -59,6 +60,7 @@ void conv_shape_dims(ConvShape s, int* cin, int* cout, int* hw);
 void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st);     // conv_bf16.hip (bf16 MFMA)
 void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st);
 void launch_conv1_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, hipStream_t st);
+void launch_conv1_pool_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, void* p_out, uint8_t* p_arg, hipStream_t st);
 void launch_conv1_wgrad_bf16(const WgradArgs& a, const unsigned short* lut16, hipStream_t st);
 int  wgrad_grid_bf16(ConvShape s, int n);                                  // -1: shape handled by conv.hip
 void launch_conv_wgrad_bf16(ConvShape s, const WgradArgs& a, hipStream_t st);

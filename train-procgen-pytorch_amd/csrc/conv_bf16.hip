@@ -529,12 +529,97 @@ __global__ __launch_bounds__(256) void conv1_fwd_bf16_kernel(ConvArgs a, const u
     }
 }
 
+// block1.conv + MaxPool2d(3,2,1) in one launch: a work item produces 4 pooled rows (x 32 x 16 ch) from 9 conv rows
+// (one halo row recomputed), which only ever exist in LDS -- the 64x64x16 conv output, the largest tensor of the
+// network, is neither written nor re-read (the backward pass needs the pooled arg-max, not the conv output).
+using C1P = C1T<9>;
+__global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, const unsigned short* lut16, unsigned short* p_out, uint8_t* p_arg) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_in[C1P::NPIX * 4];
+    __shared__ __attribute__((aligned(16))) unsigned short s_w[16 * C1_WS];
+    __shared__ __attribute__((aligned(16))) unsigned short s_c[9 * 64 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    for (int e = tid; e < 16 * C1_WS; e += 256) {
+        const int j = e / C1_WS, k = e % C1_WS, tap = k / 4, ci = k % 4;
+        s_w[e] = f2bf((k < 36 && ci < 3) ? a.w[(j * 9 + tap) * 3 + ci] : 0.f);
+    }
+    for (int e = tid; e < C1P::NPIX * 4; e += 256) s_in[e] = 0;
+    const float bias = a.bias ? a.bias[i] : 0.f;
+    int off0, off1;
+    { const int t0 = 2 * kq, t1 = 2 * kq + 1; off0 = ((t0 / 3) * C1P::PW + t0 % 3) * 4; off1 = ((t1 / 3) * C1P::PW + t1 % 3) * 4; }
+    constexpr int off8 = (2 * C1P::PW + 2) * 4;
+    const int nwork = a.n * 8;                             // 8 groups of 4 pooled rows per image
+    uint32_t regs[C1P::NLD];
+    if ((int)blockIdx.x < nwork) c1_load<C1P>(regs, (const uint8_t*)a.in, a.idx, a.in_base, blockIdx.x / 8, (blockIdx.x % 8) * 8 - 1);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int img = work / 8, oy0 = (work % 8) * 4, cy0 = 2 * oy0 - 1;      // first conv row of this item (may be -1)
+        __syncthreads();
+        c1_store<C1P>(regs, s_in, lut16);
+        __syncthreads();
+        if (work + (int)gridDim.x < nwork) { const int w2 = work + gridDim.x; c1_load<C1P>(regs, (const uint8_t*)a.in, a.idx, a.in_base, w2 / 8, (w2 % 8) * 8 - 1); }
+        const bf16x8 bw1 = *(const bf16x8*)(s_w + i * C1_WS + kq * 8);
+        const bf16x8 bw2 = *(const bf16x8*)(s_w + i * C1_WS + 32 + kq * 8);
+#pragma unroll
+        for (int mt = 0; mt < 9; ++mt) {
+            const int pl = (wave * 9 + mt) * 16 + i, y = pl / 64, x = pl % 64;
+            const unsigned short* p = s_in + (y * C1P::PW + x) * 4;
+            const uint2 lo = *(const uint2*)(p + off0), hi = *(const uint2*)(p + off1), t8 = *(const uint2*)(p + off8);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = MFMA_BF16(__builtin_bit_cast(bf16x8, (uint4){lo.x, lo.y, hi.x, hi.y}), bw1, acc);
+            acc = MFMA_BF16(__builtin_bit_cast(bf16x8, (uint4){t8.x, t8.y, 0u, 0u}), bw2, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_c[((wave * 9 + mt) * 16 + kq * 4 + r) * 16 + i] = f2bf(acc[r] + bias);
+        }
+        __syncthreads();
+        {   // pooling: thread = (pooled row 0..3, pooled col 0..31, 8-channel half)
+            const int c8 = tid & 1, ox = (tid >> 1) & 31, oyl = tid >> 6;
+            float best[8];
+            unsigned bw[4] = {0, 0, 0, 0}, bi[8];
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ly = 2 * oyl + ky, gy = cy0 + ly, x = 2 * ox - 1 + kx;
+                    if (gy < 0 || gy >= 64 || x < 0 || x >= 64) continue;
+                    const uint4 u = *(const uint4*)(s_c + (ly * 64 + x) * 16 + c8 * 8);
+                    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned bits = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu);
+                        const float v = __uint_as_float(bits << 16);
+                        if (first || v > best[k] || v != v) {
+                            best[k] = v; bi[k] = ky * 3 + kx;
+                            bw[k >> 1] = (k & 1) ? ((bw[k >> 1] & 0x0000ffffu) | (bits << 16)) : ((bw[k >> 1] & 0xffff0000u) | bits);
+                        }
+                    }
+                    first = false;
+                }
+            const size_t o = ((((size_t)img * 32 + oy0 + oyl) * 32 + ox) * 2 + c8) * 8;
+            *(uint4*)(p_out + o) = (uint4){bw[0], bw[1], bw[2], bw[3]};
+            *(uint2*)(p_arg + o) = (uint2){bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24)};
+        }
+    }
+}
+void launch_conv1_pool_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, void* p_out, uint8_t* p_arg, hipStream_t st) {
+    const int w = a.n * 8, grid = w > 1024 ? 1024 : w;
+    if (grid < 1) return;
+    hipLaunchKernelGGL(conv1_pool_fwd_bf16_kernel, dim3(grid), dim3(256), 0, st, a, lut16, (unsigned short*)p_out, p_arg);
+}
+
 constexpr int C1_SI = 48;          // im2col row stride (bf16 elements): 16 x odd -> conflict-free transpose reads
+// POOLED: a.dout is the gradient of the POOLED map (32x32x16) and a.pool_arg its arg-max bytes; the conv-output
+// gradient tile is rebuilt in LDS from the 3 pooled rows that touch the 4 conv rows of the item (max-pool backward
+// fused into the staging: no 64x64x16 gradient tensor in HBM).
+template <bool POOLED>
 __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, const unsigned short* lut16) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
-    unsigned short* s_in = smem_h;                                   // [660][4]
-    unsigned short* s_col = smem_h + ((C1W::NPIX * 4 + 7) / 8) * 8;   // [512][48] (27 real columns)
-    unsigned short* s_do = s_col + C1W::NT * C1_SI;                   // [512][16]
+    unsigned short* s_in = smem_h;                                   // [396][4]
+    unsigned short* s_col = smem_h + ((C1W::NPIX * 4 + 7) / 8) * 8;   // [256][48] (27 real columns)
+    unsigned short* s_do = s_col + C1W::NT * C1_SI;                   // [256][16]
+    unsigned short* s_pd = s_do + C1W::NT * 16;                       // POOLED: [3][32][16] pooled gradient
+    uint8_t* s_pa = (uint8_t*)(s_pd + 3 * 32 * 16);                   // POOLED: [3][32][16] arg-max bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
     const unsigned short* g_do = (const unsigned short*)a.dout;
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -545,11 +630,22 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
     uint32_t regs[C1W::NLD];
     constexpr int NDO = C1W::NT * 2 / 256;                            // NT px x 2 chunks of 8 channels
     uint4 rdo[NDO];
+    uint2 rpa = {0u, 0u};
     auto load_do = [&](int img, int ty0) {
+        if (POOLED) {                                               // 3 pooled rows x 32 x 2 halves = 192 (uint4, uint2) pairs
+            rdo[0] = (uint4){0u, 0u, 0u, 0u}; rpa = (uint2){0xffffffffu, 0xffffffffu};
+            const int pr = tid >> 6, oy = ty0 / 2 + pr;
+            if (tid < 192 && oy < 32) {
+                const size_t o = (((size_t)img * 32 + oy) * 32) * 16 + (size_t)(tid & 63) * 8;
+                rdo[0] = *(const uint4*)(g_do + o);
+                rpa = *(const uint2*)(a.pool_arg + o);
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < NDO; ++k) {
-            const int e = tid + k * 256, pl = e >> 1, c8 = e & 1;
-            rdo[k] = *(const uint4*)(g_do + (((long long)img * C1W::HW + ty0 + pl / C1W::TW) * C1W::HW + pl % C1W::TW) * 16 + c8 * 8);
+            for (int k = 0; k < NDO; ++k) {
+                const int e = tid + k * 256, pl = e >> 1, c8 = e & 1;
+                rdo[k] = *(const uint4*)(g_do + (((long long)img * C1W::HW + ty0 + pl / C1W::TW) * C1W::HW + pl % C1W::TW) * 16 + c8 * 8);
+            }
         }
     };
     if ((int)blockIdx.x < nwork) {
@@ -559,12 +655,39 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         __syncthreads();
         c1_store<C1W>(regs, s_in, lut16);
+        if (POOLED) {
+            if (tid < 192) { *(uint4*)(s_pd + tid * 8) = rdo[0]; *(uint2*)(s_pa + tid * 8) = rpa; }
+        } else {
 #pragma unroll
-        for (int k = 0; k < NDO; ++k) { const int e = tid + k * 256; *(uint4*)(s_do + (e >> 1) * 16 + (e & 1) * 8) = rdo[k]; }
+            for (int k = 0; k < NDO; ++k) { const int e = tid + k * 256; *(uint4*)(s_do + (e >> 1) * 16 + (e & 1) * 8) = rdo[k]; }
+        }
         __syncthreads();
         if (work + (int)gridDim.x < nwork) {
             const int w2 = work + gridDim.x, img = w2 / C1W::TPI, ty0 = (w2 % C1W::TPI) * C1W::TH;
             c1_load<C1W>(regs, (const uint8_t*)a.in, a.idx, a.in_base, img, ty0); load_do(img, ty0);
+        }
+        if (POOLED) {       // max-pool backward into the LDS tile: conv pixel (y, x) gathers from the <= 4 windows containing it
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = tid + h * 256, c8 = e & 1, pl = e >> 1, ly = pl / 64, x = pl % 64;
+                float sm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int oyl = ly / 2; oyl <= (ly + 1) / 2; ++oyl)             // local pooled row (tile rows start at a multiple of 4)
+                    for (int ox = x / 2; ox <= (x + 1) / 2; ++ox) {
+                        if (ox >= 32) continue;
+                        const unsigned pos = (unsigned)((ly - (2 * oyl - 1)) * 3 + (x - (2 * ox - 1)));
+                        const int o = ((oyl * 32 + ox) * 2 + c8) * 8;
+                        const uint2 ag = *(const uint2*)(s_pa + o);
+                        const uint4 d = *(const uint4*)(s_pd + o);
+                        const unsigned w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const unsigned ak = ((k < 4 ? ag.x : ag.y) >> (8 * (k & 3))) & 0xffu;
+                            if (ak == pos) sm[k] += (k & 1) ? __uint_as_float(w[k >> 1] & 0xffff0000u) : __uint_as_float(w[k >> 1] << 16);
+                        }
+                    }
+                *(uint4*)(s_do + pl * 16 + c8 * 8) = (uint4){(unsigned)f2bf(sm[0]) | ((unsigned)f2bf(sm[1]) << 16), (unsigned)f2bf(sm[2]) | ((unsigned)f2bf(sm[3]) << 16),
+                                                           (unsigned)f2bf(sm[4]) | ((unsigned)f2bf(sm[5]) << 16), (unsigned)f2bf(sm[6]) | ((unsigned)f2bf(sm[7]) << 16)};
+            }
         }
         // im2col: pixel p -> its 27 (tap, ci) values, contiguous (columns 27..31 zero)
 #pragma unroll
@@ -623,6 +746,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
     if (tid < 16) { float sum = 0.f; for (int g = 0; g < 16; ++g) sum += redb[g * 16 + tid]; slab[432 + tid] = sum; }
 }
 constexpr size_t C1_WG_LDS = (size_t)(((C1W::NPIX * 4 + 7) / 8) * 8 + C1W::NT * C1_SI + C1W::NT * 16) * 2;
+constexpr size_t C1_WGP_LDS = C1_WG_LDS + 3 * 32 * 16 * 3;
 static int c1_grid(int n) { const int w = n * C1W::TPI; return w > 1024 ? 1024 : w; }
 void launch_conv1_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, hipStream_t st) {
     const int w = a.n * C1::TPI, grid = w > 1024 ? 1024 : w;
@@ -631,10 +755,15 @@ void launch_conv1_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, hipSt
 }
 void launch_conv1_wgrad_bf16(const WgradArgs& a, const unsigned short* lut16, hipStream_t st) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)conv1_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_WG_LDS); attr = true; }
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv1_wgrad_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_WG_LDS);
+        hipFuncSetAttribute((const void*)conv1_wgrad_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_WGP_LDS);
+        attr = true;
+    }
     const int grid = c1_grid(a.n);
     if (grid < 1) return;
-    hipLaunchKernelGGL(conv1_wgrad_bf16_kernel, dim3(grid), dim3(256), C1_WG_LDS, st, a, lut16);
+    if (a.pool_arg) hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<true>, dim3(grid), dim3(256), C1_WGP_LDS, st, a, lut16);
+    else hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<false>, dim3(grid), dim3(256), C1_WG_LDS, st, a, lut16);
 }
 
 // ------------------------------------------------------------------------------------------ launchers

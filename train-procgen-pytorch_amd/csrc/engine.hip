@@ -563,8 +563,9 @@ static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const f
     ProfScope ps(c, PC_CONV_DGRAD + (int)L.shape, n, px * c->es * (L.cout + L.cin * (1 + (mask ? 1 : 0) + (res ? 1 : 0))), px * 18.0 * L.cin * L.cout);
     launch_conv_dgrad(L.shape, a, c->stream);
 }
-static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const InputSrc* src, int relu_in, const float* dout, int n) {
+static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const InputSrc* src, int relu_in, const float* dout, int n, const uint8_t* pool_arg = nullptr) {
     WgradArgs a{};
+    a.pool_arg = pool_arg;
     a.in = src ? src->base : in; a.idx = src ? src->idx : nullptr; a.in_base = src ? src->first : 0;
     a.dout = dout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
     a.lut16 = c->bf ? c->lut16 : nullptr;
@@ -572,7 +573,7 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
     if (grid < 1) return;
     if ((size_t)grid * (size_t)(L.cout * 9 * L.cin + L.cout) > c->slab_floats) { fprintf(stderr, "mi355ppo: wgrad slab workspace too small\n"); abort(); }
     const double px = (double)n * L.hw * L.hw;
-    { ProfScope ps(c, PC_CONV_WGRAD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : c->es * L.cin) + c->es * L.cout), px * 18.0 * L.cin * L.cout);
+    { ProfScope ps(c, PC_CONV_WGRAD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : c->es * L.cin) + (pool_arg ? 0.75 : 1.0) * c->es * L.cout), px * 18.0 * L.cin * L.cout);
       launch_conv_wgrad(L.shape, a, c->stream); }
     const int wlen = L.cout * 9 * L.cin;
     ProfScope ps(c, PC_SLAB_REDUCE, n, 4.0 * grid * (wlen + L.cout), 0.0);
@@ -635,10 +636,19 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
         for (int b = 0; b < 3; ++b) {
             Block& k = c->blk[b];
             const ConvLayer* L = &c->convs[b * 5];
+            if (b == 0 && c->bf) {           // block1.conv + max pool fused: the 64x64x16 conv output never reaches HBM
+                ConvArgs a{};
+                a.in = src.base; a.idx = src.idx; a.in_base = src.first; a.w = c->params + L[0].w_off; a.bias = c->params + L[0].b_off;
+                a.n = n; a.bf16 = 1; a.lut16 = c->lut16;
+                const double px = (double)n * 64 * 64;
+                ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, px * 3.0 + px / 4 * 16 * 3.0, px * 18.0 * 3 * 16);
+                launch_conv1_pool_fwd_bf16(a, c->lut16, k.P0, k.PI, c->stream);
+            } else {
             if (b == 0) conv_fwd(c, L[0], nullptr, &src, 0, nullptr, k.C, n);
             else conv_fwd(c, L[0], prev, nullptr, 0, nullptr, k.C, n);
             { ProfScope ps(c, PC_POOL_FWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
               if (c->bf) launch_maxpool_fwd_bf16(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); else launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); }
+            }
             if (c->bf) {                     // fused residual blocks; the intermediate is written only when a backward pass follows
                 const double px = (double)n * L[1].hw * L[1].hw, ch = L[1].cout;
                 for (int r = 0; r < 2; ++r) {
@@ -721,6 +731,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         conv_wgrad(c, L[1], k.P0, nullptr, 1, Ga, n);
         conv_dgrad(c, L[1], Ga, k.P0, Gb, Gout, n);
         // max pool, then the block's first conv
+        if (b == 0 && c->bf) { conv_wgrad(c, L[0], nullptr, &src, 0, Gout, n, k.PI); break; }     // pool backward fused into the staging
         { ProfScope ps(c, PC_POOL_BWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
           if (c->bf) launch_maxpool_bwd_bf16(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); else launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); }
         if (b == 0) conv_wgrad(c, L[0], nullptr, &src, 0, c->GC, n);
@@ -1062,6 +1073,39 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
     if (mode != 1) {
         if (in_is_u8) { HIPC(hipMalloc(&din, px * 3 + 256)); HIPC(hipMemcpy(din, in, px * 3, hipMemcpyHostToDevice)); }
         else if (int r = upload_act(c, (const float*)in, px * cin, &din)) return r;
+    }
+    if (mode >= 3) {        // block1.conv fused with its max pool (bf16): 3 = forward -> pooled map, 4 = weight gradient from the pooled gradient
+        ARG(s == CS_3_16_64 && c->bf, "fused conv+pool modes exist for block1.conv in bf16 precision only");
+        const size_t pp = (size_t)n * 32 * 32 * 16;
+        void* dp = nullptr; uint8_t* di = nullptr;
+        HIPC(hipMalloc(&dp, pp * 2 + 256)); HIPC(dalloc(&di, pp));
+        ConvArgs a{};
+        a.in = din; a.w = dw; a.bias = db; a.n = n; a.bf16 = 1; a.lut16 = c->lut16;
+        launch_conv1_pool_fwd_bf16(a, c->lut16, dp, di, c->stream);
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(c->stream));
+        if (mode == 3) { if (int r = download_act(c, dp, out, pp)) return r; }
+        else {
+            ARG(dout && c->slabs, "dout");
+            if (int r = upload_act(c, dout, pp, &ddout)) return r;
+            float* g = nullptr;
+            HIPC(dalloc(&g, td.n + cout));
+            WgradArgs wa{};
+            wa.in = din; wa.dout = ddout; wa.partial = c->slabs; wa.n = n; wa.bf16 = 1; wa.lut16 = c->lut16; wa.pool_arg = di;
+            const int grid = wgrad_grid_for(s, n, 1);
+            launch_conv_wgrad(s, wa, c->stream);
+            launch_reduce_slabs(c->slabs, grid, (int)td.n + cout, g, (int)td.n, g + td.n, cout, c->stream);
+            HIPC(hipGetLastError());
+            HIPC(hipStreamSynchronize(c->stream));
+            std::vector<float> hg(td.n + cout);
+            HIPC(hipMemcpy(hg.data(), g, hg.size() * 4, hipMemcpyDeviceToHost));
+            to_ref_layout(td, hg.data(), out);
+            if (dbias_out) memcpy(dbias_out, hg.data() + td.n, cout * 4);
+            hipFree(g);
+        }
+        void* fr[] = {dw, db, din, ddout, dp, di};
+        for (void* p : fr) if (p) hipFree(p);
+        return 0;
     }
     if (mode >= 1) { ARG(dout, "dout"); if (int r = upload_act(c, dout, px * cout, &ddout)) return r; }
     if (res) { if (int r = upload_act(c, res, px * out_ch, &dres)) return r; }

@@ -314,17 +314,20 @@ class Engine:
     def op_conv3x3(self, mode, cin, cout, hw, w_ref, inp=None, relu_in=False, bias=None, res=None, mask=None, dout=None):
         is_u8 = inp is not None and inp.dtype == np.uint8
         n = (inp if inp is not None else dout).shape[0]
+        # modes: 0 forward, 1 dgrad, 2 wgrad; block1.conv in bf16 precision also 3 = conv+maxpool forward, 4 = wgrad from the pooled gradient
         inp = None if inp is None else np.ascontiguousarray(inp)
         w_ref = _f32(w_ref)
         bias, res, mask, dout = (None if a is None else _f32(a) for a in (bias, res, mask, dout))
-        if mode == 2:
+        if mode in (2, 4):
             out, db = np.empty((cout, cin, 3, 3), np.float32), np.empty(cout, np.float32)
+        elif mode == 3:
+            out, db = np.empty((n, hw // 2, hw // 2, cout), np.float32), None
         else:
             out, db = np.empty((n, hw, hw, cin if mode == 1 else cout), np.float32), None
         self._chk(self.lib.mi_op_conv3x3(self._ctx, C.c_int32(mode), C.c_int32(cin), C.c_int32(cout), C.c_int32(hw),
                                          C.c_int32(n), _fp(inp), C.c_int32(int(is_u8)), C.c_int32(int(relu_in)), _fp(w_ref),
                                          _fp(bias), _fp(res), _fp(mask), _fp(dout), _fp(out), _fp(db)))
-        return (out, db) if mode == 2 else out
+        return (out, db) if mode in (2, 4) else out
 
     def op_maxpool(self, mode, x, dout=None):
         x = _f32(x)
