@@ -182,13 +182,17 @@ def main():
         for h in host_frames:
             h[...] = rng.integers(0, 256, size=h.shape, dtype=np.uint8)
 
+    phase = {"rollout_s": 0.0}
+
     def iteration(it):
+        t_r = time.perf_counter()
         for t in range(T + 1):                          # T policy steps + the bootstrap-value step
             if host_frames is not None:
                 eng.put_obs(t, host_frames[t & 3])
             # act/logp/value come back to the host every step (env.step needs act); the previous step's
             # reward / done (what env.step returned) go up with the same call
             eng.rollout_step(t, rew[t - 1] if t else None, done[t - 1] if t else None, seed=it)
+        phase["rollout_s"] += time.perf_counter() - t_r         # every rollout_step ends with its read-back: no extra sync
         storage.compute_estimates(hp["gamma"], hp["lmbda"], hp["use_gae"], hp["normalize_adv"], agent.coll)
         return agent.optimize()
 
@@ -203,6 +207,7 @@ def main():
     eng.profile_enable(2 if args.profile_rollout else 1)
     eng.profile_read(reset=True)
     fence()
+    phase["rollout_s"] = 0.0
     t0 = time.perf_counter()
     for it in range(args.steps):
         summary = iteration(args.warmup + it)
@@ -245,6 +250,7 @@ def main():
                                       f"A={A}, frames resident in HBM" + (" + per-step H2D" if args.h2d else ""),
                           "parallelism": f"dp{world} over n_envs"},
                "roofline": roof,
+               "phase_ms_per_step": {"rollout": phase["rollout_s"] / args.steps * 1e3, "update": (dt - phase["rollout_s"]) / args.steps * 1e3},
                "kernels": sorted(prof, key=lambda r: -r["ms"])[:12],
                "loss_total": summary["Loss/total"]}
         if world == 1 and not args.no_cpu_baseline:

@@ -1,5 +1,5 @@
 import csv, glob, sys
-rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + "/runc/*_kernel_trace.csv")[0])))
+rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + "/runc*kernel_trace.csv")[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("heads_sample")]
 a, b = idx[-150], idx[-149]

@@ -183,3 +183,13 @@ def test_lr_schedule_and_config():
     hp = cfg["hard-500"]
     assert (hp["n_envs"], hp["n_steps"], hp["mini_batch_size"], hp["epoch"]) == (256, 256, 8192, 3)
     assert cfg["easy"]["mini_batch_size"] == 2048 and cfg["cartpole"]["architecture"] == "mlpmodel"
+
+
+def test_frame_byte_to_bf16_needs_no_table():
+    """block1.conv (bf16 mode) stages a frame byte k as bf16(k/255).  The kernel computes k * fp32(1/255) and rounds to
+    bf16 (csrc/conv_bf16.hip c1_store); for all 256 bytes that equals rounding the correctly-rounded fp32 quotient
+    (what the reference's ScaledFloatFrame produces before a bf16 cast)."""
+    k = torch.arange(256, dtype=torch.float32)
+    quotient = (k / 255.0).bfloat16()
+    product = (k * torch.tensor(1.0 / 255.0, dtype=torch.float32)).bfloat16()
+    assert torch.equal(quotient.view(torch.int16), product.view(torch.int16))

@@ -242,6 +242,17 @@ void launch_pack_banks(const float* params, unsigned short* banks, const BankDes
 // while the staged tiles are [pixel][channel]: the fragments come through ds_read_b64_tr_b16 (the LDS transpose
 // read), two per operand per MFMA.  Accumulators (one 16x16 tile per tap / co-block / ci-block) stay in registers
 // across the persistent loop; waves are summed through LDS in fixed order; one slab per workgroup.
+// tuning knobs of the 32 -> 32 weight-gradient kernels (scratch/kbench.hip sweeps them): min waves per SIMD the
+// compiler must leave room for, tile height at 16x16, images per item at 8x8
+#ifndef WG_WPE
+#define WG_WPE 2
+#endif
+#ifndef WG16_TH          // tile height of the 16x16 / images per item of the 8x8 weight-gradient kernels (scratch/kbench.hip sweeps them)
+#define WG16_TH 16
+#endif
+#ifndef WG8_NIMG
+#define WG8_NIMG 4
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
@@ -258,34 +269,95 @@ struct WbCfg {
     static constexpr int C8 = CIN / 8, OC8 = COUT / 8;
     static constexpr int NLD = (NPIX * C8 + 255) / 256, NDO = (NT * OC8 + 255) / 256;
     static constexpr int TPI_X = HW / TW, TPI = (HW / TH) * (HW / TW);
-    static constexpr size_t TILE_BYTES = (size_t)(IN_ELEMS + DO_ELEMS) * 2, RED_BYTES = (size_t)(WLEN + 256) * 4;
+    // SPLIT (32 -> 32 channels): the 18 (tap, input block) column tiles are dealt round-robin to the 4 waves, every wave
+    // walks ALL pixel steps with 10 accumulator tiles instead of 36 (312 -> ~110 registers: 1 -> 2+ waves per SIMD) and
+    // owns its outputs outright, so the cross-wave reduction through LDS disappears as well.
+    static constexpr bool SPLIT = (CIN == 32 && COUT == 32);
+    static constexpr int NQ = 9 * NIB, QMAX = (NQ + 3) / 4;
+    static constexpr size_t TILE_BYTES = (size_t)(IN_ELEMS + DO_ELEMS) * 2, RED_BYTES = (size_t)((SPLIT ? 0 : WLEN) + 256) * 4;
     static constexpr size_t LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
     static_assert(NT % 32 == 0, "pixel steps of 32");
 };
 
+#ifdef WG_TIMING      // scratch/kbench.hip: per-phase shader-clock totals of wave 0, summed over workgroups
+__device__ unsigned long long g_wg_timing[8];
+#define TCK(k) do { if (tid == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
+#else
+#define TCK(k) do { } while (0)
+#endif
+
 template <class C>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, C::SPLIT ? WG_WPE : 1) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+#ifdef WG_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
+#endif
     unsigned short* s_in = smem_h;
     unsigned short* s_do = smem_h + C::IN_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
     const unsigned short* g_in = (const unsigned short*)a.in;
     const unsigned short* g_do = (const unsigned short*)a.dout;
-    f32x4 acc[9 * C::NCB * C::NIB];
+    constexpr int NACC = C::SPLIT ? C::QMAX * C::NCB : 9 * C::NCB * C::NIB;
+    f32x4 acc[NACC];
 #pragma unroll
-    for (int k = 0; k < 9 * C::NCB * C::NIB; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-    const int bc = tid % C::COUT, bg = tid / C::COUT;
-    constexpr int BG = 256 / C::COUT;
+    for (int k = 0; k < NACC; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wv = __builtin_amdgcn_readfirstlane(wave);          // wave-uniform copy (SGPR): SPLIT column ownership
+    const int qcnt = (C::NQ - wv + 3) / 4;                         // columns q = wv + 4*qq, qq < qcnt
+    // bias gradient = row sums of the dOut operand: one extra MFMA against an all-ones B tile (exact: x * 1.0, fp32 adds)
+    f32x4 accb[C::NCB];
+#pragma unroll
+    for (int cb = 0; cb < C::NCB; ++cb) accb[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
     const int nwork = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
     uint4 rin[C::NLD], rdo[C::NDO];
+    // whole-image tiles: a thread's source offsets inside the item never change -> computed once (-1 = halo outside the image)
+    int ioff[C::TPI == 1 ? C::NLD : 1], doff[C::TPI == 1 ? C::NDO : 1];
+    if constexpr (C::TPI == 1) {
+#pragma unroll
+        for (int k = 0; k < C::NLD; ++k) {
+            const int e = tid + k * 256;
+            ioff[k] = -1;
+            if (e < C::NPIX * C::C8) {
+                const int pix = e / C::C8, c8 = e % C::C8, img = pix / (C::PH * C::PW), q = pix % (C::PH * C::PW);
+                const int gy = q / C::PW - 1, gx = q % C::PW - 1;
+                if (gy >= 0 && gy < C::HW && gx >= 0 && gx < C::HW) ioff[k] = ((img * C::HW + gy) * C::HW + gx) * C::CIN + c8 * 8;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < C::NDO; ++k) {
+            const int e = tid + k * 256;
+            doff[k] = -1;
+            if (e < C::NT * C::OC8) {
+                const int pl = e / C::OC8, c8 = e % C::OC8, y = pl / C::TW, x = pl % C::TW;
+                doff[k] = (((y / C::TH) * C::HW + (y % C::TH)) * C::HW + x) * C::COUT + c8 * 8;
+            }
+        }
+    }
     auto coords = [&](int work, int& img0, int& ty0, int& tx0) {
         if (C::NIMG > 1) { img0 = work * C::NIMG; ty0 = 0; tx0 = 0; }
         else { img0 = work / C::TPI; const int t = work % C::TPI; ty0 = (t / C::TPI_X) * C::TH; tx0 = (t % C::TPI_X) * C::TW; }
     };
     auto load = [&](int img0, int ty0, int tx0) {
+        if constexpr (C::TPI == 1) {
+            const int left = a.n - img0;                                      // images of this item that exist
+            const unsigned short* bi = g_in + (long long)img0 * (C::HW * C::HW * C::CIN);
+            const unsigned short* bd = g_do + (long long)img0 * (C::HW * C::HW * C::COUT);
+#pragma unroll
+            for (int k = 0; k < C::NLD; ++k) {
+                uint4 v = {0u, 0u, 0u, 0u};
+                if (ioff[k] >= 0 && (C::NIMG == 1 || ioff[k] / (C::HW * C::HW * C::CIN) < left)) v = *(const uint4*)(bi + ioff[k]);
+                rin[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < C::NDO; ++k) {
+                uint4 v = {0u, 0u, 0u, 0u};
+                if (doff[k] >= 0 && (C::NIMG == 1 || doff[k] / (C::HW * C::HW * C::COUT) < left)) v = *(const uint4*)(bd + doff[k]);
+                rdo[k] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < C::NLD; ++k) {
             const int e = tid + k * 256;
@@ -312,8 +384,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
     };
     int img0, ty0, tx0;
     if ((int)blockIdx.x < nwork) { coords(blockIdx.x, img0, ty0, tx0); load(img0, ty0, tx0); }
+    TCK(0);
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         __syncthreads();
+        TCK(1);
 #pragma unroll
         for (int k = 0; k < C::NLD; ++k) {
             const int e = tid + k * 256;
@@ -328,9 +402,46 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
             const int e = tid + k * 256;
             if (e < C::NT * C::OC8) *(uint4*)(s_do + (e / C::OC8) * C::SO + (e % C::OC8) * 8) = rdo[k];
         }
+        TCK(2);
         __syncthreads();
+        TCK(3);
         if (work + (int)gridDim.x < nwork) { coords(work + gridDim.x, img0, ty0, tx0); load(img0, ty0, tx0); }
+        TCK(4);
 
+        if constexpr (C::SPLIT) {
+#pragma unroll
+            for (int t = 0; t < C::NSTEP; ++t) {
+                int drow[2], irow[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pl = 32 * t + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq, y = pl / C::TW, x = pl % C::TW;
+                    drow[h] = pl * C::SO + 4 * cp;
+                    irow[h] = (((y / C::TH) * C::PH + (y % C::TH)) * C::PW + x) * C::S + 4 * cp;
+                }
+                bf16x8 av[C::NCB];
+#pragma unroll
+                for (int cb = 0; cb < C::NCB; ++cb) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + drow[0] + cb * 16));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + drow[1] + cb * 16));
+                    av[cb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int cb = 0; cb < C::NCB; ++cb)
+                    if (wv == 2 + cb) accb[cb] = MFMA_BF16(av[cb], ones, accb[cb]);       // waves 2, 3 own one column fewer
+#pragma unroll
+                for (int qq = 0; qq < C::QMAX; ++qq) {
+                    if (qq < qcnt) {                                  // wave-uniform: EXEC stays full for the transpose reads
+                        const int q = wv + 4 * qq, tap = q / C::NIB, ib = q % C::NIB;
+                        const int toff = ((tap / 3) * C::PW + (tap % 3)) * C::S + ib * 16;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_in + irow[0] + toff));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_in + irow[1] + toff));
+                        const bf16x8 bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int cb = 0; cb < C::NCB; ++cb) acc[qq * C::NCB + cb] = MFMA_BF16(av[cb], bv, acc[qq * C::NCB + cb]);
+                    }
+                }
+            }
+        } else
         for (int t = wave; t < C::NSTEP; t += 4) {
             // this lane's two source rows (pixels) of the 4x16 transpose blocks.  MFMA k index = 8*kq + 4*h + rq; the
             // pixel it stands for is a free (A/B-consistent) permutation: 16*(kq>>1) + 8*h + 4*(kq&1) + rq
@@ -347,6 +458,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + drow[0] + cb * 16));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + drow[1] + cb * 16));
                 av[cb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                accb[cb] = MFMA_BF16(av[cb], ones, accb[cb]);
             }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -362,10 +474,33 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
                 }
             }
         }
-        for (int p = bg; p < C::NT; p += BG) bsum += bf2f(s_do[p * C::SO + bc]);
+        TCK(5);
     }
 
     __syncthreads();
+    if constexpr (C::SPLIT) {
+        float* slab = a.partial + (long long)blockIdx.x * C::SLAB;
+#pragma unroll
+        for (int qq = 0; qq < C::QMAX; ++qq)
+            if (qq < qcnt) {
+                const int q = wv + 4 * qq, tap = q / C::NIB, ib = q % C::NIB;
+#pragma unroll
+                for (int cb = 0; cb < C::NCB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[((cb * 16 + kq * 4 + r) * 9 + tap) * C::CIN + ib * 16 + i] = acc[qq * C::NCB + cb][r];
+            }
+#pragma unroll
+        for (int cb = 0; cb < C::NCB; ++cb)
+            if (wv == 2 + cb && i == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[C::WLEN + cb * 16 + kq * 4 + r] = accb[cb][r];
+            }
+        TCK(7);
+#ifdef WG_TIMING
+        if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_wg_timing[k], (unsigned long long)tacc_[k]);
+#endif
+        return;
+    }
     float* red = (float*)smem_h;
     float* redb = red + C::WLEN;
     for (int w = 0; w < 4; ++w) {
@@ -385,22 +520,23 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
         }
         __syncthreads();
     }
-    redb[tid] = bsum;
+    if (i == 0) {
+#pragma unroll
+        for (int cb = 0; cb < C::NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) redb[wave * C::COUT + cb * 16 + kq * 4 + r] = accb[cb][r];
+    }
     __syncthreads();
     float* slab = a.partial + (long long)blockIdx.x * C::SLAB;
     for (int e = tid; e < C::WLEN; e += 256) slab[e] = red[e];
-    if (tid < C::COUT) {
-        float sum = 0.f;
-        for (int g = 0; g < BG; ++g) sum += redb[g * C::COUT + tid];
-        slab[C::WLEN + tid] = sum;
-    }
+    if (tid < C::COUT) slab[C::WLEN + tid] = (redb[tid] + redb[C::COUT + tid]) + (redb[2 * C::COUT + tid] + redb[3 * C::COUT + tid]);
 }
 
 //                          CIN COUT HW  TH  TW NIMG
 using WT_16_16_32 = WbCfg<16, 16, 32,  8, 32, 1>;
 using WT_16_32_32 = WbCfg<16, 32, 32,  8, 32, 1>;
-using WT_32_32_16 = WbCfg<32, 32, 16, 16, 16, 1>;
-using WT_32_32_8  = WbCfg<32, 32,  8,  8,  8, 4>;
+using WT_32_32_16 = WbCfg<32, 32, 16, WG16_TH, 16, 1>;
+using WT_32_32_8  = WbCfg<32, 32,  8,  8,  8, WG8_NIMG>;
 
 template <class C>
 static int wb_grid(int n) {
@@ -447,40 +583,35 @@ void launch_conv_wgrad_bf16(ConvShape s, const WgradArgs& a, hipStream_t st) {
 template <int TH_>
 struct C1T {
     static constexpr int HW = 64, TH = TH_, TW = 64, PH = TH + 2, PW = 66, NPIX = PH * PW, NT = TH * TW;
-    static constexpr int ROW_DW = HW * 3 / 4, NLD = (PH * ROW_DW + 255) / 256;       // frame rows as dwords
+    static constexpr int NTASK = PH * 16, NLD = 3;      // a task = 12 frame bytes = 4 pixels (3 dwords in, 4 x 8 bytes out)
     static constexpr int TPI = HW / TH;
+    static_assert(NTASK <= 256, "one staging task per thread");
 };
 using C1 = C1T<8>;          // forward tile
 using C1W = C1T<4>;         // weight-gradient tile (smaller LDS footprint -> 4 workgroups per CU)
 template <class C1>
 __device__ __forceinline__ void c1_load(uint32_t (&r)[C1::NLD], const uint8_t* frames, const int32_t* idx, long long in_base, int img, int ty0) {
-#pragma unroll
-    for (int k = 0; k < C1::NLD; ++k) {
-        const int e = threadIdx.x + k * 256;
-        uint32_t v = 0u;
-        if (e < C1::PH * C1::ROW_DW) {
-            const int row = e / C1::ROW_DW, dw = e % C1::ROW_DW, gy = ty0 + row - 1;
-            if (gy >= 0 && gy < C1::HW) {
-                const long long frame = idx ? (long long)idx[img] : in_base + img;
-                v = *(const uint32_t*)(frames + frame * (C1::HW * C1::HW * 3) + gy * (C1::HW * 3) + dw * 4);
-            }
-        }
-        r[k] = v;
+    const int e = threadIdx.x, row = e >> 4, g = e & 15, gy = ty0 + row - 1;
+    r[0] = r[1] = r[2] = 0u;
+    if (e < C1::NTASK && gy >= 0 && gy < C1::HW) {
+        const long long frame = idx ? (long long)idx[img] : in_base + img;
+        const uint32_t* p = (const uint32_t*)(frames + frame * (C1::HW * C1::HW * 3) + gy * (C1::HW * 3) + g * 12);
+        r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
     }
 }
+// uint8 -> bf16(k/255): k * (1/255) rounded to bf16 equals the bf16 of the exact quotient for all 256 values (checked
+// exhaustively on the host, tests/test_host_logic.py), so no table: 12 converts + 4 8-byte LDS stores per task.
 template <class C1>
-__device__ __forceinline__ void c1_store(const uint32_t (&r)[C1::NLD], unsigned short* s_in, const unsigned short* lut16) {
+__device__ __forceinline__ void c1_store(const uint32_t (&r)[C1::NLD], unsigned short* s_in, const unsigned short*) {
+    const int e = threadIdx.x, row = e >> 4, g = e & 15;
+    if (e < C1::NTASK) {
+        float f[12];
 #pragma unroll
-    for (int k = 0; k < C1::NLD; ++k) {
-        const int e = threadIdx.x + k * 256;
-        if (e < C1::PH * C1::ROW_DW) {
-            const int row = e / C1::ROW_DW, dw = e % C1::ROW_DW;
+        for (int b = 0; b < 12; ++b) f[b] = (float)((r[b >> 2] >> (8 * (b & 3))) & 0xffu) * (1.0f / 255.0f);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int byte = dw * 4 + b, px = byte / 3, ch = byte % 3;
-                s_in[(row * C1::PW + 1 + px) * 4 + ch] = lut16[(r[k] >> (8 * b)) & 0xffu];      // lut16[0] == 0: padded rows
-            }
-        }
+        for (int j = 0; j < 4; ++j)
+            *(uint2*)(s_in + (row * C1::PW + 1 + g * 4 + j) * 4) =
+                (uint2){(unsigned)f2bf(f[3 * j]) | ((unsigned)f2bf(f[3 * j + 1]) << 16), (unsigned)f2bf(f[3 * j + 2])};
     }
 }
 
@@ -538,12 +669,17 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
     __shared__ __attribute__((aligned(16))) unsigned short s_w[16 * C1_WS];
     __shared__ __attribute__((aligned(16))) unsigned short s_c[9 * 64 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+#ifdef WG_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
+#endif
     for (int e = tid; e < 16 * C1_WS; e += 256) {
         const int j = e / C1_WS, k = e % C1_WS, tap = k / 4, ci = k % 4;
         s_w[e] = f2bf((k < 36 && ci < 3) ? a.w[(j * 9 + tap) * 3 + ci] : 0.f);
     }
     for (int e = tid; e < C1P::NPIX * 4; e += 256) s_in[e] = 0;
-    const float bias = a.bias ? a.bias[i] : 0.f;
+    float bias4[4];                                        // output channels 4*kq .. 4*kq+3 (the MFMA's row quad)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[r] = a.bias ? a.bias[kq * 4 + r] : 0.f;
     int off0, off1;
     { const int t0 = 2 * kq, t1 = 2 * kq + 1; off0 = ((t0 / 3) * C1P::PW + t0 % 3) * 4; off1 = ((t1 / 3) * C1P::PW + t1 % 3) * 4; }
     constexpr int off8 = (2 * C1P::PW + 2) * 4;
@@ -552,10 +688,15 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
     if ((int)blockIdx.x < nwork) c1_load<C1P>(regs, (const uint8_t*)a.in, a.idx, a.in_base, blockIdx.x / 8, (blockIdx.x % 8) * 8 - 1);
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         const int img = work / 8, oy0 = (work % 8) * 4, cy0 = 2 * oy0 - 1;      // first conv row of this item (may be -1)
+        TCK(0);
         __syncthreads();
+        TCK(1);
         c1_store<C1P>(regs, s_in, lut16);
+        TCK(2);
         __syncthreads();
+        TCK(3);
         if (work + (int)gridDim.x < nwork) { const int w2 = work + gridDim.x; c1_load<C1P>(regs, (const uint8_t*)a.in, a.idx, a.in_base, w2 / 8, (w2 % 8) * 8 - 1); }
+        TCK(4);
         const bf16x8 bw1 = *(const bf16x8*)(s_w + i * C1_WS + kq * 8);
         const bf16x8 bw2 = *(const bf16x8*)(s_w + i * C1_WS + 32 + kq * 8);
 #pragma unroll
@@ -563,44 +704,61 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
             const int pl = (wave * 9 + mt) * 16 + i, y = pl / 64, x = pl % 64;
             const unsigned short* p = s_in + (y * C1P::PW + x) * 4;
             const uint2 lo = *(const uint2*)(p + off0), hi = *(const uint2*)(p + off1), t8 = *(const uint2*)(p + off8);
+            // operands swapped (A = filter rows, B = pixels): the lane then holds 4 CONSECUTIVE channels of one pixel ->
+            // one 8-byte LDS store per tile instead of four 2-byte ones
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = MFMA_BF16(__builtin_bit_cast(bf16x8, (uint4){lo.x, lo.y, hi.x, hi.y}), bw1, acc);
-            acc = MFMA_BF16(__builtin_bit_cast(bf16x8, (uint4){t8.x, t8.y, 0u, 0u}), bw2, acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_c[((wave * 9 + mt) * 16 + kq * 4 + r) * 16 + i] = f2bf(acc[r] + bias);
+            acc = MFMA_BF16(bw1, __builtin_bit_cast(bf16x8, (uint4){lo.x, lo.y, hi.x, hi.y}), acc);
+            acc = MFMA_BF16(bw2, __builtin_bit_cast(bf16x8, (uint4){t8.x, t8.y, 0u, 0u}), acc);
+            *(uint2*)(s_c + ((wave * 9 + mt) * 16 + i) * 16 + kq * 4) =
+                (uint2){(unsigned)f2bf(acc[0] + bias4[0]) | ((unsigned)f2bf(acc[1] + bias4[1]) << 16),
+                        (unsigned)f2bf(acc[2] + bias4[2]) | ((unsigned)f2bf(acc[3] + bias4[3]) << 16)};
         }
+        TCK(5);
         __syncthreads();
-        {   // pooling: thread = (pooled row 0..3, pooled col 0..31, 8-channel half)
+        TCK(6);
+        {   // pooling: thread = (pooled row 0..3, pooled col 0..31, 8-channel half).  All 9 window reads are issued up
+            // front (clamped addresses); a window position outside the image (top row of the image, left column) is
+            // masked, and the first VALID position is always taken -- the rule of the stand-alone max-pool kernel.
             const int c8 = tid & 1, ox = (tid >> 1) & 31, oyl = tid >> 6;
-            float best[8];
-            unsigned bw[4] = {0, 0, 0, 0}, bi[8];
-            bool first = true;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+            const int ky0 = (cy0 + 2 * oyl < 0) ? 1 : 0, kx0 = (ox == 0) ? 1 : 0;
+            uint4 u[9];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int ly = 2 * oyl + ky, gy = cy0 + ly, x = 2 * ox - 1 + kx;
-                    if (gy < 0 || gy >= 64 || x < 0 || x >= 64) continue;
-                    const uint4 u = *(const uint4*)(s_c + (ly * 64 + x) * 16 + c8 * 8);
-                    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+                    const int x = 2 * ox - 1 + kx;
+                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * 64 + (x < 0 ? 0 : x)) * 16 + c8 * 8);
+                }
+            float best[8];
+            unsigned bi[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const unsigned bits = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu);
-                        const float v = __uint_as_float(bits << 16);
-                        if (first || v > best[k] || v != v) {
-                            best[k] = v; bi[k] = ky * 3 + kx;
-                            bw[k >> 1] = (k & 1) ? ((bw[k >> 1] & 0x0000ffffu) | (bits << 16)) : ((bw[k >> 1] & 0xffff0000u) | bits);
-                        }
+            for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bool valid = (ky >= ky0) && (kx >= kx0), isfirst = (ky == ky0) && (kx == kx0);
+                    const unsigned w[4] = {u[ky * 3 + kx].x, u[ky * 3 + kx].y, u[ky * 3 + kx].z, u[ky * 3 + kx].w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float v = (q & 1) ? __uint_as_float(w[q >> 1] & 0xffff0000u) : __uint_as_float(w[q >> 1] << 16);
+                        if (valid && (isfirst || v > best[q] || v != v)) { best[q] = v; bi[q] = ky * 3 + kx; }
                     }
-                    first = false;
                 }
             const size_t o = ((((size_t)img * 32 + oy0 + oyl) * 32 + ox) * 2 + c8) * 8;
-            *(uint4*)(p_out + o) = (uint4){bw[0], bw[1], bw[2], bw[3]};
+            uint4 pk;                                        // best[] are bf16 values widened to fp32: the high halves are the bits
+            pk.x = (__float_as_uint(best[0]) >> 16) | (__float_as_uint(best[1]) & 0xffff0000u);
+            pk.y = (__float_as_uint(best[2]) >> 16) | (__float_as_uint(best[3]) & 0xffff0000u);
+            pk.z = (__float_as_uint(best[4]) >> 16) | (__float_as_uint(best[5]) & 0xffff0000u);
+            pk.w = (__float_as_uint(best[6]) >> 16) | (__float_as_uint(best[7]) & 0xffff0000u);
+            *(uint4*)(p_out + o) = pk;
             *(uint2*)(p_arg + o) = (uint2){bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24)};
         }
+        TCK(7);
     }
+#ifdef WG_TIMING
+    if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_wg_timing[k], (unsigned long long)tacc_[k]);
+#endif
 }
 void launch_conv1_pool_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, void* p_out, uint8_t* p_arg, hipStream_t st) {
     const int w = a.n * 8, grid = w > 1024 ? 1024 : w;
@@ -622,9 +780,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
     uint8_t* s_pa = (uint8_t*)(s_pd + 3 * 32 * 16);                   // POOLED: [3][32][16] arg-max bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
     const unsigned short* g_do = (const unsigned short*)a.dout;
+#ifdef WG_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
+#endif
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float bsum = 0.f;
-    const int bc = tid & 15, bg = tid >> 4;
     for (int e = tid; e < C1W::NPIX * 4; e += 256) s_in[e] = 0;
     const int nwork = a.n * C1W::TPI;
     uint32_t regs[C1W::NLD];
@@ -653,7 +812,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
         c1_load<C1W>(regs, (const uint8_t*)a.in, a.idx, a.in_base, img, ty0); load_do(img, ty0);
     }
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        TCK(0);
         __syncthreads();
+        TCK(1);
         c1_store<C1W>(regs, s_in, lut16);
         if (POOLED) {
             if (tid < 192) { *(uint4*)(s_pd + tid * 8) = rdo[0]; *(uint2*)(s_pa + tid * 8) = rpa; }
@@ -661,34 +822,54 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
 #pragma unroll
             for (int k = 0; k < NDO; ++k) { const int e = tid + k * 256; *(uint4*)(s_do + (e >> 1) * 16 + (e & 1) * 8) = rdo[k]; }
         }
+        TCK(2);
         __syncthreads();
         if (work + (int)gridDim.x < nwork) {
             const int w2 = work + gridDim.x, img = w2 / C1W::TPI, ty0 = (w2 % C1W::TPI) * C1W::TH;
             c1_load<C1W>(regs, (const uint8_t*)a.in, a.idx, a.in_base, img, ty0); load_do(img, ty0);
         }
-        if (POOLED) {       // max-pool backward into the LDS tile: conv pixel (y, x) gathers from the <= 4 windows containing it
+        TCK(3);
+        if (POOLED) {       // max-pool backward into the LDS tile.  A thread owns a 2x2 block of conv pixels x 4 channels: the
+            // 4 windows (oy, ox) in {a, a+1} x {b, b+1} that touch the block are read once each and their 9 (window, pixel)
+            // incidences -- one per pool position -- are resolved with compile-time (ky, kx); windows are added in
+            // (oy, ox) order, the order of the stand-alone max-pool backward kernel.
+            const int cq = tid & 3, bx = (tid >> 2) & 31, by = tid >> 7;
+            float sm[4][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int e = tid + h * 256, c8 = e & 1, pl = e >> 1, ly = pl / 64, x = pl % 64;
-                float sm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int oyl = ly / 2; oyl <= (ly + 1) / 2; ++oyl)             // local pooled row (tile rows start at a multiple of 4)
-                    for (int ox = x / 2; ox <= (x + 1) / 2; ++ox) {
-                        if (ox >= 32) continue;
-                        const unsigned pos = (unsigned)((ly - (2 * oyl - 1)) * 3 + (x - (2 * ox - 1)));
-                        const int o = ((oyl * 32 + ox) * 2 + c8) * 8;
-                        const uint2 ag = *(const uint2*)(s_pa + o);
-                        const uint4 d = *(const uint4*)(s_pd + o);
-                        const unsigned w[4] = {d.x, d.y, d.z, d.w};
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const unsigned ak = ((k < 4 ? ag.x : ag.y) >> (8 * (k & 3))) & 0xffu;
-                            if (ak == pos) sm[k] += (k & 1) ? __uint_as_float(w[k >> 1] & 0xffff0000u) : __uint_as_float(w[k >> 1] << 16);
+                for (int c = 0; c < 4; ++c) sm[q][c] = 0.f;
+#pragma unroll
+            for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+                for (int wx = 0; wx < 2; ++wx) {
+                    const int o = ((by + wy) * 32 + bx + wx) * 16 + cq * 4;
+                    const uint2 d = *(const uint2*)(s_pd + o);
+                    unsigned ag = *(const unsigned*)(s_pa + o);
+                    if (wx == 1 && bx == 31) ag = 0xffffffffu;                 // window column 32 does not exist
+                    const float v[4] = {__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u), __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u)};
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int ky = dy + 1 - 2 * wy, kx = dx + 1 - 2 * wx;
+                            if (ky < 0 || kx < 0) continue;
+                            const unsigned pos = (unsigned)(ky * 3 + kx);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (((ag >> (8 * c)) & 0xffu) == pos) sm[dy * 2 + dx][c] += v[c];
                         }
-                    }
-                *(uint4*)(s_do + pl * 16 + c8 * 8) = (uint4){(unsigned)f2bf(sm[0]) | ((unsigned)f2bf(sm[1]) << 16), (unsigned)f2bf(sm[2]) | ((unsigned)f2bf(sm[3]) << 16),
-                                                           (unsigned)f2bf(sm[4]) | ((unsigned)f2bf(sm[5]) << 16), (unsigned)f2bf(sm[6]) | ((unsigned)f2bf(sm[7]) << 16)};
-            }
+                }
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float* q = sm[dy * 2 + dx];
+                    *(uint2*)(s_do + ((2 * by + dy) * 64 + 2 * bx + dx) * 16 + cq * 4) =
+                        (uint2){(unsigned)f2bf(q[0]) | ((unsigned)f2bf(q[1]) << 16), (unsigned)f2bf(q[2]) | ((unsigned)f2bf(q[3]) << 16)};
+                }
         }
+        TCK(4);
         // im2col: pixel p -> its 27 (tap, ci) values, contiguous (columns 27..31 zero)
 #pragma unroll
         for (int h = 0; h < C1W::NT / 256; ++h) {
@@ -696,6 +877,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
             unsigned short v[32];
 #pragma unroll
             for (int k = 27; k < 32; ++k) v[k] = 0;
+            v[27] = 0x3f80;                                           // column 27 = 1.0: its output column is the bias gradient
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const uint2 t = *(const uint2*)(s_in + ((y + tap / 3) * C1W::PW + x + tap % 3) * 4);
@@ -707,6 +889,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
                 d[k] = (uint4){(unsigned)v[8 * k] | ((unsigned)v[8 * k + 1] << 16), (unsigned)v[8 * k + 2] | ((unsigned)v[8 * k + 3] << 16),
                                (unsigned)v[8 * k + 4] | ((unsigned)v[8 * k + 5] << 16), (unsigned)v[8 * k + 6] | ((unsigned)v[8 * k + 7] << 16)};
         }
+        TCK(5);
         __syncthreads();
         for (int t = wave; t < C1W::NT / 32; t += 4) {
             int row[2];
@@ -722,11 +905,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
                 acc[ib] = MFMA_BF16(av, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), acc[ib]);
             }
         }
-        for (int p = bg; p < C1W::NT; p += 16) bsum += bf2f(s_do[p * 16 + bc]);
+        TCK(6);
     }
+#ifdef WG_TIMING
+    if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_wg_timing[k], (unsigned long long)tacc_[k]);
+#endif
     __syncthreads();
-    float* red = (float*)smem_h;                 // 432 weights + 256 bias partials
-    float* redb = red + 432;
+    float* red = (float*)smem_h;                 // 432 weights + 16 bias sums (the ones column)
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -734,16 +919,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int jj = ib * 16 + i;
-                    if (jj < 27) { const int o = (kq * 4 + r) * 27 + jj; red[o] = (w == 0) ? acc[ib][r] : red[o] + acc[ib][r]; }
+                    if (jj <= 27) { const int o = (jj < 27) ? (kq * 4 + r) * 27 + jj : 432 + kq * 4 + r; red[o] = (w == 0) ? acc[ib][r] : red[o] + acc[ib][r]; }
                 }
         }
         __syncthreads();
     }
-    redb[tid] = bsum;
-    __syncthreads();
     float* slab = a.partial + (long long)blockIdx.x * 448;
-    for (int e = tid; e < 432; e += 256) slab[e] = red[e];
-    if (tid < 16) { float sum = 0.f; for (int g = 0; g < 16; ++g) sum += redb[g * 16 + tid]; slab[432 + tid] = sum; }
+    for (int e = tid; e < 448; e += 256) slab[e] = red[e];
 }
 constexpr size_t C1_WG_LDS = (size_t)(((C1W::NPIX * 4 + 7) / 8) * 8 + C1W::NT * C1_SI + C1W::NT * 16) * 2;
 constexpr size_t C1_WGP_LDS = C1_WG_LDS + 3 * 32 * 16 * 3;
