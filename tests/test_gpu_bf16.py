@@ -219,3 +219,23 @@ def test_fc_bf16_matrix_core_path_matches_small_batch_path():
         a, b = grads[0][k].astype(np.float64).ravel(), grads[1][k].astype(np.float64).ravel()
         rel = np.linalg.norm(a - b) / np.linalg.norm(b)
         assert rel < 1e-1, (k, rel)          # deepest layer measured 3.5e-2: bf16 rounding of d(feat) + of every dgrad output below it
+
+
+def test_fc_small_batch_kernel_matches_tiled_kernel():
+    """embedder.fc has two bf16 kernels: the 128x64-tiled one for update-sized batches and the latency-oriented one for
+    rollout-sized batches (n < 1024: one 16x16 output tile per workgroup, K split over the 4 waves).  Same packed
+    weights, same bf16 products, fp32 accumulation in a different order -> equal to accumulation-order noise."""
+    from mi355 import layout
+    from mi355.engine import Engine
+    z = load_npz("g3_impala_forward.npz")
+    flat = layout.flatten(layout.impala_param_shapes(15), npz_params(z))
+    eng = Engine("impala", 2, 8, 15, 1024, precision="bf16")
+    eng.set_params(flat)
+    frames = np.random.default_rng(3).integers(0, 256, size=(1024, 64, 64, 3), dtype=np.uint8)
+    lp_big, v_big, f_big = eng.forward(frames, want_feat=True)
+    lp_small, v_small, f_small = eng.forward(frames[:40], want_feat=True)          # 2 full groups of 16 envs + a ragged one
+    eng.close()
+    assert np.abs(f_big).max() > 1e-2
+    np.testing.assert_allclose(f_small, f_big[:40], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(lp_small, lp_big[:40], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(v_small, v_big[:40], rtol=1e-4, atol=1e-5)

@@ -136,6 +136,7 @@ void launch_gru_gates(const float* gi, const float* gh, const float* hm, float* 
 
 // ---------------------------------------------------------------- embedder.fc on the bf16 matrix cores (fc_bf16.hip)
 struct FcNtArgs;
+void launch_fc_fwd_small_bf16(const void* X, const unsigned short* Wp, const float* bias, float* feat, int n, hipStream_t st);
 void launch_fc_pack(const float* w, unsigned short* wp, unsigned short* wt, int N, int K, hipStream_t st);
 void launch_fc_fwd_bf16(const void* x_bf16, const unsigned short* wp, const float* bias, float* y, int n, hipStream_t st);
 void launch_fc_dgrad_bf16(const float* dy, const unsigned short* wt, const void* mask_bf16, void* dx_bf16, int n, hipStream_t st);

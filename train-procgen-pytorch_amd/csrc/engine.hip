@@ -666,10 +666,10 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
             }
             prev = k.P2;
         }
-        if (c->bf && n >= 1024) {               // update-sized batches: bf16 matrix cores (fc_bf16.hip)
-            fc_refresh(c);
+        if (c->bf) {                            // bf16 matrix cores on the packed [256][2048] weight image (fc_bf16.hip)
             ProfScope ps(c, PC_GEMM, n, 2.0 * n * 2048 + 2.0 * 2048 * 256 + 4.0 * n * 256, 2.0 * n * 2048 * 256);
-            launch_fc_fwd_bf16(c->blk[2].P2, c->fc_wp, c->params + c->fc.b_off, c->feat, n, c->stream);
+            if (n >= 1024) launch_fc_fwd_bf16(c->blk[2].P2, c->fc_wp, c->params + c->fc.b_off, c->feat, n, c->stream);
+            else launch_fc_fwd_small_bf16(c->blk[2].P2, c->fc_wp, c->params + c->fc.b_off, c->feat, n, c->stream);   // rollout-sized: latency-bound
         } else
             linear_fwd(c, c->blk[2].P2, 1, c->params + c->fc.w_off, c->params + c->fc.b_off, c->feat, n, 2048, c->H, 1, c->bf);
     } else {
@@ -772,9 +772,10 @@ int mi_rollout_step(mi_ctx* c, int32_t t, const float* rew_prev, const float* do
     const int E = c->E;
     if (rew_prev || done_prev) {
         ARG(rew_prev && done_prev && t >= 1, "rew_prev/done_prev come together and belong to step t-1");
+        // pinned, device-visible staging: the head kernel reads {rew, done} straight from host memory and writes its
+        // packed result straight back -- no copy kernels on the step's critical path (the stream sync below fences both)
         memcpy(c->h_rd, rew_prev, (size_t)E * 4); memcpy(c->h_rd + E, done_prev, (size_t)E * 4);
-        HIPC(hipMemcpyAsync(c->d_rd, c->h_rd, (size_t)2 * E * 4, hipMemcpyHostToDevice, c->stream));
-        if (c->gru_on) HIPC(hipMemcpyAsync(c->d_done, c->d_rd + E, (size_t)E * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (c->gru_on) HIPC(hipMemcpyAsync(c->d_done, c->h_rd + E, (size_t)E * 4, hipMemcpyHostToDevice, c->stream));
     }
     const bool have_rd = rew_prev != nullptr;
     InputSrc src{c->frames ? (const void*)c->frames : (const void*)c->obsf, nullptr, (long long)t * E};
@@ -785,11 +786,10 @@ int mi_rollout_step(mi_ctx* c, int32_t t, const float* rew_prev, const float* do
     const bool last = (t == c->T);
     launch_heads_sample(c->feat, c->params + c->wh_off, c->params + c->bh_off, E, c->H, c->A, du, seed, (unsigned long long)t * E,
                         last ? nullptr : c->act + (size_t)t * E, last ? nullptr : c->logp + (size_t)t * E, c->value + (size_t)t * E,
-                        c->d_pack, nullptr, have_rd ? c->d_rd : nullptr, have_rd ? c->rew + (size_t)(t - 1) * E : nullptr,
+                        c->h_pack, nullptr, have_rd ? c->h_rd : nullptr, have_rd ? c->rew + (size_t)(t - 1) * E : nullptr,
                         have_rd ? c->done + (size_t)(t - 1) * E : nullptr, c->stream);
     HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(c->h_pack, c->d_pack, (size_t)3 * E * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));             // also covers the h_rd / u staging reuse
+    HIPC(hipStreamSynchronize(c->stream));             // kernel end = system-scope release of h_pack; also covers h_rd / u reuse
     for (int e = 0; e < E; ++e) {
         if (act_out && !last) act_out[e] = (int64_t)c->h_pack[3 * e];
         if (logp_out && !last) logp_out[e] = c->h_pack[3 * e + 1];

@@ -241,3 +241,39 @@ void launch_fc_dgrad_bf16(const float* dy, const unsigned short* wt, const void*
     g.a_f32 = 1; g.relu_a = 0; g.relu_out = 0; g.c_bf16 = 1;
     launch_fc_nt(g, st);
 }
+
+// ------------------------------------------------------------------------------------------ small-batch forward (rollout)
+// n = E (256) rows: latency-bound, so the work is spread over (n/16) x (256/16) workgroups.  A workgroup owns a 16 x 16
+// output tile; its 4 waves split K = 2048 (16 MFMA steps each), every lane loads exactly its own operand fragments
+// straight from global memory / L2 (all 32 loads in flight before the first MFMA), the 4 partial tiles are summed through
+// LDS in fixed order, + bias, ReLU.
+__global__ __launch_bounds__(256) void fc_small_bf16_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp,
+                                                            const float* __restrict__ bias, float* __restrict__ feat, int n) {
+    __shared__ float red[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int e0 = blockIdx.y * 16, o0 = blockIdx.x * 16;
+    const int env = e0 + i;
+    const unsigned short* xa = X + (long long)(env < n ? env : n - 1) * 2048 + wave * 512 + kq * 8;
+    const unsigned short* wb = Wp + (long long)(o0 + i) * 2048 + wave * 512 + kq * 8;
+    uint4 ra[16], rb[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { ra[s] = *(const uint4*)(xa + s * 32); rb[s] = *(const uint4*)(wb + s * 32); }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const uint4 a = {fc_relu2(ra[s].x), fc_relu2(ra[s].y), fc_relu2(ra[s].z), fc_relu2(ra[s].w)};
+        acc = MFMA_BF16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, rb[s]), acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(kq * 4 + r) * 16 + i] = acc[r];
+    __syncthreads();
+    const int row = tid >> 4, col = tid & 15;
+    if (e0 + row < n) {
+        const float v = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + bias[o0 + col];
+        feat[(long long)(e0 + row) * 256 + o0 + col] = v > 0.f ? v : 0.f;
+    }
+}
+void launch_fc_fwd_small_bf16(const void* X, const unsigned short* Wp, const float* bias, float* feat, int n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fc_small_bf16_kernel, dim3(16, (n + 15) / 16), dim3(256), 0, st, (const unsigned short*)X, Wp, bias, feat, n);
+}

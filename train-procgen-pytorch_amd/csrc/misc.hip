@@ -702,6 +702,13 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
     __shared__ __attribute__((aligned(16))) float s_f[16 * 260];
     __shared__ float s_z[16 * 17];
     const int tid = threadIdx.x, e0 = blockIdx.x * 16;
+    if ((H & 3) == 0) {
+        const int H4 = H >> 2;
+        for (int k = tid; k < 16 * H4; k += 256) {
+            const int el = k / H4, kk = (k % H4) * 4;
+            *(f32x4*)(s_f + el * 260 + kk) = (e0 + el < n) ? *(const f32x4*)(feat + (long long)(e0 + el) * H + kk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    } else
     for (int k = tid; k < 16 * H; k += 256) {
         const int el = k / H, kk = k % H;
         s_f[el * 260 + kk] = (e0 + el < n) ? feat[(long long)(e0 + el) * H + kk] : 0.f;
@@ -711,12 +718,26 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
     for (int oo = o; oo <= A; oo += 16) {                 // A+1 <= 17 outputs: output 16 (if any) is taken by o == 0
         const float* w = Wh + (long long)oo * H;
         float acc = 0.f;
-        int k = 0;
-        for (; k + 4 <= H; k += 4) {                       // H is 256 (IMPALA) or 64 (MLP): 16-byte aligned rows
-            const f32x4 f = *(const f32x4*)(s_f + el * 260 + k), ww = *(const f32x4*)(w + k);
-            acc += f.x * ww.x + f.y * ww.y + f.z * ww.z + f.w * ww.w;
+        if (H == 256) {                                    // IMPALA: fully unrolled, 16 weight loads in flight per batch
+#pragma unroll
+            for (int kb = 0; kb < 256; kb += 64) {
+                f32x4 ww[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) ww[q] = *(const f32x4*)(w + kb + q * 4);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const f32x4 f = *(const f32x4*)(s_f + el * 260 + kb + q * 4);
+                    acc += f.x * ww[q].x + f.y * ww[q].y + f.z * ww[q].z + f.w * ww[q].w;
+                }
+            }
+        } else {
+            int k = 0;
+            for (; k + 4 <= H; k += 4) {                   // MLP widths: 16-byte aligned rows
+                const f32x4 f = *(const f32x4*)(s_f + el * 260 + k), ww = *(const f32x4*)(w + k);
+                acc += f.x * ww.x + f.y * ww.y + f.z * ww.z + f.w * ww.w;
+            }
+            for (; k < H; ++k) acc += s_f[el * 260 + k] * w[k];
         }
-        for (; k < H; ++k) acc += s_f[el * 260 + k] * w[k];
         s_z[el * 17 + oo] = acc + bh[oo];
     }
     __syncthreads();
