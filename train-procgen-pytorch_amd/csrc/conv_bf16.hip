@@ -106,9 +106,14 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a) {
         s_w[e] = f2bf(v);
     }
 
-    float bias_r[C::NB];
+    // The MFMA runs with the FILTER rows as its A operand and the pixels as B: a lane's 4 accumulator registers are then 4
+    // CONSECUTIVE output channels (4*kq .. 4*kq+3 of the block) of ONE pixel (lane & 15), so mask / residual / output move
+    // as 8-byte words -- a wave's store covers whole 32- or 64-byte pixels back to back.
+    float bias_r[C::NB][4];
 #pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb) bias_r[nb] = a.bias ? a.bias[nb * 16 + i] : 0.f;
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_r[nb][r] = a.bias ? a.bias[nb * 16 + kq * 4 + r] : 0.f;
     // per-lane A offsets of the NK K-steps: tap offset + 8-channel chunk
     int koff[C::NK];
 #pragma unroll
@@ -133,46 +138,38 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a) {
             bf_tile_load<C>(regs, g_in, a.n, i2, y2, x2);
         }
         // epilogue operands requested before the MFMA phase (one wave-uniform branch per block of loads)
-        unsigned short e_mask[C::MT][4][C::NB], e_res[C::MT][4][C::NB];
-        long long e_off[C::MT][4];
+        uint2 e_mask[C::MT][C::NB], e_res[C::MT][C::NB];
+        long long e_off[C::MT];
+        bool e_on[C::MT];
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pl = (wave * C::MT + mt) * 16 + kq * 4 + r, y = pl / C::TW, x = pl % C::TW;
-                int n = img0 + y / C::TH;
-                n = n < a.n ? n : a.n - 1;
-                e_off[mt][r] = (((long long)n * C::HW + ty0 + (y % C::TH)) * C::HW + tx0 + x) * C::COUT + i;
-            }
+        for (int mt = 0; mt < C::MT; ++mt) {
+            const int pl = (wave * C::MT + mt) * 16 + i, y = pl / C::TW, x = pl % C::TW;
+            int n = img0 + y / C::TH;
+            e_on[mt] = n < a.n;
+            n = n < a.n ? n : a.n - 1;
+            e_off[mt] = (((long long)n * C::HW + ty0 + (y % C::TH)) * C::HW + tx0 + x) * C::COUT + kq * 4;
+        }
         if (g_mask) {
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][r][nb] = g_mask[e_off[mt][r] + nb * 16];
+                for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][nb] = *(const uint2*)(g_mask + e_off[mt] + nb * 16);
         } else {
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][r][nb] = 0x3f80;      // 1.0
+                for (int nb = 0; nb < C::NB; ++nb) e_mask[mt][nb] = (uint2){0x3f803f80u, 0x3f803f80u};      // 1.0
         }
         if (g_res) {
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) e_res[mt][r][nb] = g_res[e_off[mt][r] + nb * 16];
+                for (int nb = 0; nb < C::NB; ++nb) e_res[mt][nb] = *(const uint2*)(g_res + e_off[mt] + nb * 16);
         } else {
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) e_res[mt][r][nb] = 0;
+                for (int nb = 0; nb < C::NB; ++nb) e_res[mt][nb] = (uint2){0u, 0u};
         }
 
         f32x4 acc[C::MT][C::NB];
@@ -197,22 +194,25 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a) {
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(av[mt], bv[nb], acc[mt][nb]);
+                for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);
         }
 
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
+            if (e_on[mt]) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pl = (wave * C::MT + mt) * 16 + kq * 4 + r, y = pl / C::TW;
-                if (img0 + y / C::TH < a.n) {
+                for (int nb = 0; nb < C::NB; ++nb) {
+                    const unsigned mw[2] = {e_mask[mt][nb].x, e_mask[mt][nb].y}, rw[2] = {e_res[mt][nb].x, e_res[mt][nb].y};
+                    float v[4];
 #pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) {
-                        float v = acc[mt][nb][r] + bias_r[nb];
-                        v = bf2f(e_mask[mt][r][nb]) > 0.f ? v : 0.f;
-                        v += bf2f(e_res[mt][r][nb]);
-                        g_out[e_off[mt][r] + nb * 16] = f2bf(v);
+                    for (int r = 0; r < 4; ++r) {
+                        const float mk = (r & 1) ? __uint_as_float(mw[r >> 1] & 0xffff0000u) : __uint_as_float(mw[r >> 1] << 16);
+                        const float rs = (r & 1) ? __uint_as_float(rw[r >> 1] & 0xffff0000u) : __uint_as_float(rw[r >> 1] << 16);
+                        v[r] = acc[mt][nb][r] + bias_r[nb][r];
+                        v[r] = mk > 0.f ? v[r] : 0.f;
+                        v[r] += rs;
                     }
+                    *(uint2*)(g_out + e_off[mt] + nb * 16) = (uint2){(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
                 }
             }
     }

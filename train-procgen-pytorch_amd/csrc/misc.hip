@@ -691,74 +691,94 @@ __device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigne
     return (float)(c[0] >> 8) * (1.0f / 16777216.0f);     // [0,1), 24 bits
 }
 // Rollout head, fused: policy/value heads (common/policy.py:74-80) + log-softmax + sample + log_prob
-// (agents/ppo.py:77-79) for one env per wave; results also packed [n][3] = {act, logp, value} for ONE read-back.
-// 16 envs per workgroup: the 16 feature rows go through LDS, thread (env, output) owns one dot product, then one
-// thread per env normalises and samples.
+// (agents/ppo.py:77-79); results also packed [n][3] = {act, logp, value} for ONE read-back.
+// 16 envs per workgroup: feature rows AND the (A+1) x H head matrix go through LDS, thread (env, output) owns one dot
+// product and then one ACTION of the normalisation: the exp / log terms are computed one per lane, every sum is still
+// taken in action order 0..A-1 (each lane re-adds the terms from LDS), so the numbers are those of the sequential
+// log_softmax_twice + CDF walk of sample_kernel.
 __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restrict__ feat, const float* __restrict__ Wh,
                                                            const float* __restrict__ bh, int n, int H, int A, const float* u,
                                                            unsigned long long seed, unsigned long long ctr, int32_t* act,
                                                            float* logp, float* value, float* pack, float* hout,
                                                            const float* rd, float* rew_dst, float* done_dst) {
     __shared__ __attribute__((aligned(16))) float s_f[16 * 260];
+    __shared__ __attribute__((aligned(16))) float s_w[17 * 260];
     __shared__ float s_z[16 * 17];
+    __shared__ float s_e[16 * 16];
     const int tid = threadIdx.x, e0 = blockIdx.x * 16;
+    const int el = tid >> 4, o = tid & 15, e = e0 + el;
+    float rwd = 0.f, dn = 0.f;
+    if (rd && o == 0 && e < n) { rwd = rd[e]; dn = rd[n + e]; }          // (host-visible staging) issued first: latency hidden by the dots
     if ((H & 3) == 0) {
         const int H4 = H >> 2;
         for (int k = tid; k < 16 * H4; k += 256) {
-            const int el = k / H4, kk = (k % H4) * 4;
-            *(f32x4*)(s_f + el * 260 + kk) = (e0 + el < n) ? *(const f32x4*)(feat + (long long)(e0 + el) * H + kk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int r = k / H4, kk = (k % H4) * 4;
+            *(f32x4*)(s_f + r * 260 + kk) = (e0 + r < n) ? *(const f32x4*)(feat + (long long)(e0 + r) * H + kk) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    } else
-    for (int k = tid; k < 16 * H; k += 256) {
-        const int el = k / H, kk = k % H;
-        s_f[el * 260 + kk] = (e0 + el < n) ? feat[(long long)(e0 + el) * H + kk] : 0.f;
+        for (int k = tid; k < (A + 1) * H4; k += 256) {
+            const int r = k / H4, kk = (k % H4) * 4;
+            *(f32x4*)(s_w + r * 260 + kk) = *(const f32x4*)(Wh + (long long)r * H + kk);
+        }
+    } else {
+        for (int k = tid; k < 16 * H; k += 256) { const int r = k / H, kk = k % H; s_f[r * 260 + kk] = (e0 + r < n) ? feat[(long long)(e0 + r) * H + kk] : 0.f; }
+        for (int k = tid; k < (A + 1) * H; k += 256) { const int r = k / H, kk = k % H; s_w[r * 260 + kk] = Wh[(long long)r * H + kk]; }
     }
     __syncthreads();
-    const int el = tid >> 4, o = tid & 15;
     for (int oo = o; oo <= A; oo += 16) {                 // A+1 <= 17 outputs: output 16 (if any) is taken by o == 0
-        const float* w = Wh + (long long)oo * H;
+        const float* w = s_w + oo * 260;
+        const float* f = s_f + el * 260;
         float acc = 0.f;
-        if (H == 256) {                                    // IMPALA: fully unrolled, 16 weight loads in flight per batch
-#pragma unroll
-            for (int kb = 0; kb < 256; kb += 64) {
-                f32x4 ww[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) ww[q] = *(const f32x4*)(w + kb + q * 4);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const f32x4 f = *(const f32x4*)(s_f + el * 260 + kb + q * 4);
-                    acc += f.x * ww[q].x + f.y * ww[q].y + f.z * ww[q].z + f.w * ww[q].w;
-                }
-            }
-        } else {
-            int k = 0;
-            for (; k + 4 <= H; k += 4) {                   // MLP widths: 16-byte aligned rows
-                const f32x4 f = *(const f32x4*)(s_f + el * 260 + k), ww = *(const f32x4*)(w + k);
-                acc += f.x * ww.x + f.y * ww.y + f.z * ww.z + f.w * ww.w;
-            }
-            for (; k < H; ++k) acc += s_f[el * 260 + k] * w[k];
+        int k = 0;
+        for (; k + 4 <= H; k += 4) {
+            const f32x4 fv = *(const f32x4*)(f + k), ww = *(const f32x4*)(w + k);
+            acc += fv.x * ww.x + fv.y * ww.y + fv.z * ww.z + fv.w * ww.w;
         }
+        for (; k < H; ++k) acc += f[k] * w[k];
         s_z[el * 17 + oo] = acc + bh[oo];
     }
     __syncthreads();
-    if (tid >= 16) return;
-    const int e = e0 + tid;
-    if (e >= n) return;
-    if (rd) { rew_dst[e] = rd[e]; done_dst[e] = rd[n + e]; }     // previous step's reward / done into the (T,E) arrays
-    float z[MAXA], lp[MAXA], p[MAXA];
-    for (int k = 0; k < A; ++k) z[k] = s_z[tid * 17 + k];
-    log_softmax_twice(z, A, lp, p);
-    const float uu = u ? u[e] : philox_uniform(seed, ctr + e);
+    const bool lane_on = o < A;
+    const float z = lane_on ? s_z[el * 17 + o] : 0.f;
+    float mx = s_z[el * 17];
+    for (int k = 1; k < A; ++k) mx = fmaxf(mx, s_z[el * 17 + k]);
+    auto group_sum = [&](float term) {                    // sum over the env's A lanes, in action order
+        __syncthreads();
+        s_e[el * 16 + o] = term;
+        __syncthreads();
+        float t = 0.f;
+        for (int k = 0; k < A; ++k) t += s_e[el * 16 + k];
+        return t;
+    };
+    const float s1 = group_sum(lane_on ? expf(z - mx) : 0.f);
+    float lp = z - (mx + logf(s1));
+    const float s2 = group_sum(lane_on ? expf(lp) : 0.f);
+    lp -= logf(s2);                                        // Categorical(logits=log_probs) normalises again (policy.py:86-87)
+    const float pr = lane_on ? expf(lp) : 0.f;
+    __syncthreads();
+    s_e[el * 16 + o] = pr;
+    __syncthreads();
     float cdf = 0.f;
-    int a_sel = 0;
-    for (int k = 0; k < A; ++k) { cdf += expf(lp[k]); if (cdf <= uu) a_sel = k + 1; }
+    for (int k = 0; k <= o; ++k) cdf += s_e[el * 16 + k];
+    const float uu = (e < n) ? (u ? u[e] : philox_uniform(seed, ctr + e)) : 0.f;
+    const float mark = (lane_on && cdf <= uu) ? (float)(o + 1) : 0.f;
+    __syncthreads();
+    s_e[el * 16 + o] = mark;
+    __syncthreads();
+    float sel = 0.f;
+    for (int k = 0; k < A; ++k) sel = fmaxf(sel, s_e[el * 16 + k]);
+    int a_sel = (int)sel;
     if (a_sel > A - 1) a_sel = A - 1;
-    const float val = s_z[tid * 17 + A];
+    __syncthreads();
+    s_e[el * 16 + o] = lp;
+    __syncthreads();
+    if (o != 0 || e >= n) return;
+    const float lp_sel = s_e[el * 16 + a_sel], val = s_z[el * 17 + A];
+    if (rd) { rew_dst[e] = rwd; done_dst[e] = dn; }        // previous step's reward / done into the (T,E) arrays
     if (act) act[e] = a_sel;
-    if (logp) logp[e] = lp[a_sel];
+    if (logp) logp[e] = lp_sel;
     if (value) value[e] = val;
-    if (pack) { pack[e * 3] = (float)a_sel; pack[e * 3 + 1] = lp[a_sel]; pack[e * 3 + 2] = val; }
-    if (hout) for (int k = 0; k <= A; ++k) hout[(long long)e * (A + 1) + k] = s_z[tid * 17 + k];
+    if (pack) { pack[e * 3] = (float)a_sel; pack[e * 3 + 1] = lp_sel; pack[e * 3 + 2] = val; }
+    if (hout) for (int k = 0; k <= A; ++k) hout[(long long)e * (A + 1) + k] = s_z[el * 17 + k];
 }
 void launch_heads_sample(const float* feat, const float* Wh, const float* bh, int n, int H, int A, const float* u,
                          unsigned long long seed, unsigned long long ctr, int32_t* act, float* logp, float* value, float* pack,

@@ -68,7 +68,7 @@ __device__ __forceinline__ void rb_conv(const unsigned short* s_src, const unsig
 #pragma unroll
         for (int mt = 0; mt < C::MTC; ++mt)
 #pragma unroll
-            for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(av[mt], bv[nb], acc[mt][nb]);
+            for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);      // filters as A: 4 channels of one pixel per lane
     }
 }
 
@@ -87,9 +87,11 @@ __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
         rb_stage_weights<C>(s_w2, a.w2);
     }
     for (int e = tid; e < 2 * C::IMG_ELEMS / 8; e += 256) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // zero halos (interiors are rewritten)
-    float b1r[C::NB], b2r[C::NB];
+    float b1r[C::NB][4], b2r[C::NB][4];                   // channels nb*16 + 4*kq + r: the accumulator quad of this lane
 #pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb) { b1r[nb] = a.b1[nb * 16 + i]; b2r[nb] = a.b2[nb * 16 + i]; }
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { b1r[nb][r] = a.b1[nb * 16 + kq * 4 + r]; b2r[nb][r] = a.b2[nb * 16 + kq * 4 + r]; }
     int koff[C::NK];
 #pragma unroll
     for (int m = 0; m < C::NK; ++m) {
@@ -134,47 +136,52 @@ __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
             f32x4 acc[C::MTC][C::NB];
             rb_conv<C>(s_x, s_w1, koff, mt0, wave, i, kq, acc);
 #pragma unroll
-            for (int mt = 0; mt < C::MTC; ++mt)
+            for (int mt = 0; mt < C::MTC; ++mt) {
+                const int pl = (wave * C::MT + mt0 + mt) * 16 + i, y = pl / C::HW, x = pl % C::HW, img = y / C::HW, n = img0 + img;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pl = (wave * C::MT + mt0 + mt) * 16 + kq * 4 + r, y = pl / C::HW, x = pl % C::HW, img = y / C::HW, n = img0 + img;
+                for (int nb = 0; nb < C::NB; ++nb) {
+                    unsigned short h[4];
 #pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) {
-                        const float v = acc[mt][nb][r] + b1r[nb];
-                        const unsigned short h = rb_f2bf(v);
-                        if (a.a_out && n < a.n) a.a_out[((long long)img0 * C::HW * C::HW + pl) * C::C + nb * 16 + i] = h;
-                        s_y[((img * C::P + (y % C::HW) + 1) * C::P + x + 1) * C::S + nb * 16 + i] = (h & 0x8000u) ? (unsigned short)0 : h;
-                    }
+                    for (int r = 0; r < 4; ++r) h[r] = rb_f2bf(acc[mt][nb][r] + b1r[nb][r]);
+                    const uint2 raw = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+                    if (a.a_out && n < a.n) *(uint2*)(a.a_out + ((long long)img0 * C::HW * C::HW + pl) * C::C + nb * 16 + kq * 4) = raw;
+                    *(uint2*)(s_y + ((img * C::P + (y % C::HW) + 1) * C::P + x + 1) * C::S + nb * 16 + kq * 4) = (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};
                 }
+            }
         }
         __syncthreads();
         // ---- conv2 + residual -> y
 #pragma unroll 1
         for (int mt0 = 0; mt0 < C::MT; mt0 += C::MTC) {
-            unsigned short e_res[C::MTC][4][C::NB];
+            uint2 e_res[C::MTC][C::NB];
 #pragma unroll
-            for (int mt = 0; mt < C::MTC; ++mt)
+            for (int mt = 0; mt < C::MTC; ++mt) {
+                const int pl = (wave * C::MT + mt0 + mt) * 16 + i;
+                const int n = img0 + pl / (C::HW * C::HW);
+                const long long o = ((long long)(n < a.n ? img0 : 0) * C::HW * C::HW + (n < a.n ? pl : 0)) * C::C + kq * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pl = (wave * C::MT + mt0 + mt) * 16 + kq * 4 + r;
-                    int n = img0 + pl / (C::HW * C::HW);
-                    const long long o = ((long long)(n < a.n ? img0 : 0) * C::HW * C::HW + (n < a.n ? pl : 0)) * C::C + i;
-#pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) e_res[mt][r][nb] = a.x[o + nb * 16];        // raw x (L2-resident: just staged)
-                }
+                for (int nb = 0; nb < C::NB; ++nb) e_res[mt][nb] = *(const uint2*)(a.x + o + nb * 16);        // raw x (L2-resident: just staged)
+            }
             f32x4 acc[C::MTC][C::NB];
             rb_conv<C>(s_y, s_w2, koff, mt0, wave, i, kq, acc);
 #pragma unroll
-            for (int mt = 0; mt < C::MTC; ++mt)
+            for (int mt = 0; mt < C::MTC; ++mt) {
+                const int pl = (wave * C::MT + mt0 + mt) * 16 + i, n = img0 + pl / (C::HW * C::HW);
+                if (n < a.n) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pl = (wave * C::MT + mt0 + mt) * 16 + kq * 4 + r, n = img0 + pl / (C::HW * C::HW);
-                    if (n < a.n) {
+                    for (int nb = 0; nb < C::NB; ++nb) {
+                        const unsigned rw[2] = {e_res[mt][nb].x, e_res[mt][nb].y};
+                        unsigned short h[4];
 #pragma unroll
-                        for (int nb = 0; nb < C::NB; ++nb)
-                            a.y_out[((long long)img0 * C::HW * C::HW + pl) * C::C + nb * 16 + i] = rb_f2bf(acc[mt][nb][r] + b2r[nb] + rb_bf2f(e_res[mt][r][nb]));
+                        for (int r = 0; r < 4; ++r) {
+                            const float rs = (r & 1) ? __uint_as_float(rw[r >> 1] & 0xffff0000u) : __uint_as_float(rw[r >> 1] << 16);
+                            h[r] = rb_f2bf(acc[mt][nb][r] + b2r[nb][r] + rs);
+                        }
+                        *(uint2*)(a.y_out + ((long long)img0 * C::HW * C::HW + pl) * C::C + nb * 16 + kq * 4) =
+                            (uint2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
                     }
                 }
+            }
         }
     }
 }
