@@ -251,7 +251,7 @@ def main():
                           "parallelism": f"dp{world} over n_envs"},
                "roofline": roof,
                "phase_ms_per_step": {"rollout": phase["rollout_s"] / args.steps * 1e3, "update": (dt - phase["rollout_s"]) / args.steps * 1e3},
-               "kernels": sorted(prof, key=lambda r: -r["ms"])[:12],
+               "kernels": sorted(prof, key=lambda r: -r["ms"])[:24],
                "loss_total": summary["Loss/total"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, args.cpu_sample, args.cpu_threads or host_cores())

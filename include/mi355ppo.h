@@ -152,6 +152,11 @@ int mi_op_conv3x3(mi_ctx* ctx, int32_t mode /*0 fwd,1 dgrad,2 wgrad; block1.conv
                   const void* in, int32_t in_is_u8, int32_t relu_in, const float* w_ref /*[cout][cin][3][3]*/,
                   const float* bias, const float* res, const float* mask, const float* dout,
                   float* out /*fwd/dgrad: activations; wgrad: [cout][cin][3][3]*/, float* dbias_out);
+/* bf16 precision only: the fused residual-block kernels.  mode 0 forward (x, w1, b1, w2, b2 -> out_a = conv1 output,
+ * out_y = block output); mode 1 data gradients (x = dy, a_fwd, x_fwd, w1, w2 -> out_a = d conv1-output, out_y = d block-input).
+ * Replaces ResidualBlock.forward and its autograd (common/model.py:141-146). */
+int mi_op_resblock(mi_ctx* ctx, int32_t mode, int32_t ch, int32_t hw, int32_t n, const float* x, const float* w1, const float* b1,
+                   const float* w2, const float* b2, const float* a_fwd, const float* x_fwd, float* out_a, float* out_y);
 int mi_op_maxpool(mi_ctx* ctx, int32_t mode /*0 fwd,1 bwd*/, int32_t n, int32_t hw, int32_t c,
                   const float* in, const float* dout, float* out);
 int mi_op_gemm(mi_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak,

@@ -110,6 +110,27 @@ def test_block1_conv_pool_fused_bf16(eng, n):
     assert relerr(gb, dc.sum(dim=(0, 2, 3)).numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("ch,hw", [(16, 32), (32, 16), (32, 8)])
+@pytest.mark.parametrize("n", [1, 6])
+def test_fused_residual_block_bf16(eng, ch, hw, n):
+    """ResidualBlock (common/model.py:141-146) forward and its two data gradients, one launch each.  The torch
+    reference rounds where the kernels round: filters to bf16, conv1's output (forward) / its gradient (backward) to
+    bf16 before the second conv consumes it."""
+    g = torch.Generator().manual_seed(100 + ch + hw)
+    w1, w2 = torch.randn(ch, ch, 3, 3, generator=g) * 0.15, torch.randn(ch, ch, 3, 3, generator=g) * 0.15
+    b1, b2 = torch.randn(ch, generator=g), torch.randn(ch, generator=g)
+    x = r16(torch.randn(n, ch, hw, hw, generator=g))
+    a = r16(F.conv2d(F.relu(x), r16(w1), b1, padding=1))
+    y = F.conv2d(F.relu(a), r16(w2), b2, padding=1) + x
+    oa, oy = eng.op_resblock(0, nhwc(x), w1.numpy(), w2.numpy(), b1=b1.numpy(), b2=b2.numpy())
+    assert relerr(oa, nhwc(a)) < 1e-2 and relerr(oy, nhwc(y)) < 1e-2
+    dy = r16(torch.randn(n, ch, hw, hw, generator=g))
+    da = r16(torch.nn.grad.conv2d_input(a.shape, r16(w2), dy, padding=1) * (a > 0))
+    dx = torch.nn.grad.conv2d_input(x.shape, r16(w1), da, padding=1) * (x > 0) + dy
+    ga, gx = eng.op_resblock(1, nhwc(dy), w1.numpy(), w2.numpy(), a_fwd=nhwc(a), x_fwd=nhwc(x))
+    assert relerr(ga, nhwc(da)) < 1e-2 and relerr(gx, nhwc(dx)) < 1e-2
+
+
 @pytest.mark.parametrize("hw,c", [(64, 16), (32, 32), (16, 32)])
 def test_maxpool_bf16(eng, hw, c):
     g = torch.Generator().manual_seed(hw)

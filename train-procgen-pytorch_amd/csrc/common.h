@@ -143,8 +143,10 @@ void launch_fc_dgrad_bf16(const float* dy, const unsigned short* wt, const void*
 void launch_fc_tn(const float* A, const unsigned short* B, float* gW, float* ws, size_t ws_floats, int M, int N, int K, hipStream_t st);
 
 // fused residual block forward, bf16 mode (resblock_bf16.hip); s = ConvShape of the block's convs
-void launch_resblock_bf16(ConvShape s, const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* a_out,
-                          void* y_out, int n, const unsigned short* bank1, const unsigned short* bank2, hipStream_t st);
+void launch_resblock_bf16(ConvShape s, const void* x, const float* b1, const float* b2, void* a_out, void* y_out, int n,
+                          const unsigned short* bank1, const unsigned short* bank2, hipStream_t st);
+void launch_resblock_bwd_bf16(ConvShape s, const void* dy, const void* a_fwd, const void* x_fwd, void* da_out, void* dx_out, int n,
+                              const unsigned short* bank2_t, const unsigned short* bank1_t, hipStream_t st);
 // pre-packed bf16 filter banks: [rows][WS] with WS = NK*32+16, K laid out tap-major (conv_bf16.hip); rows = output
 // channels of the pass (dgrad: transposed + tap-mirrored view).  One descriptor per bank, device-resident.
 struct BankDesc { long long w_off, out_off; int rows, cin_pass, co_f, ci_f, transw, ws, nk; };

@@ -41,13 +41,14 @@ struct Block { float *C, *P0, *A1, *P1, *A2, *P2; uint8_t* PI; int cin, cout, hi
 struct Linear { int64_t w_off, b_off; int in, out; };
 
 // ---- live kernel timing (bench.py roofline leg)
-enum ProfClass { PC_CONV_FWD = 0, PC_CONV_DGRAD = 5, PC_CONV_WGRAD = 10, PC_POOL_FWD = 15, PC_POOL_BWD, PC_GEMM, PC_SLAB_REDUCE, PC_RESBLOCK, PC_COUNT = PC_RESBLOCK + 5 };
+enum ProfClass { PC_CONV_FWD = 0, PC_CONV_DGRAD = 5, PC_CONV_WGRAD = 10, PC_POOL_FWD = 15, PC_POOL_BWD, PC_GEMM, PC_SLAB_REDUCE, PC_RESBLOCK, PC_RESBLOCK_BWD = PC_RESBLOCK + 5, PC_COUNT = PC_RESBLOCK_BWD + 5 };
 static const char* kProfNames[PC_COUNT] = {
     "conv_fwd_3_16_64", "conv_fwd_16_16_32", "conv_fwd_16_32_32", "conv_fwd_32_32_16", "conv_fwd_32_32_8",
     "conv_dgrad_3_16_64(unused)", "conv_dgrad_16_16_32", "conv_dgrad_16_32_32", "conv_dgrad_32_32_16", "conv_dgrad_32_32_8",
     "conv_wgrad_3_16_64", "conv_wgrad_16_16_32", "conv_wgrad_16_32_32", "conv_wgrad_32_32_16", "conv_wgrad_32_32_8",
     "maxpool_fwd", "maxpool_bwd", "gemm", "slab_reduce",
-    "resblock_fwd_(unused)", "resblock_fwd_16_16_32", "resblock_fwd_(unused)", "resblock_fwd_32_32_16", "resblock_fwd_32_32_8"};
+    "resblock_fwd_(unused)", "resblock_fwd_16_16_32", "resblock_fwd_(unused)", "resblock_fwd_32_32_16", "resblock_fwd_32_32_8",
+    "resblock_dgrad_(unused)", "resblock_dgrad_16_16_32", "resblock_dgrad_(unused)", "resblock_dgrad_32_32_16", "resblock_dgrad_32_32_8"};
 struct ProfPending { hipEvent_t a, b; int cls, phase; long long units; double bytes, flops; };
 struct Profiler {
     bool on = false;
@@ -655,7 +656,7 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
                     const ConvLayer &l1 = L[1 + 2 * r], &l2 = L[2 + 2 * r];
                     float* x = r ? k.P1 : k.P0; float* a_out = train ? (r ? k.A2 : k.A1) : nullptr; float* y = r ? k.P2 : k.P1;
                     ProfScope ps(c, PC_RESBLOCK + (int)l1.shape, n, px * ch * 2.0 * (train ? 3 : 2), 2.0 * px * 18.0 * ch * ch);
-                    launch_resblock_bf16(l1.shape, x, c->params + l1.w_off, c->params + l1.b_off, c->params + l2.w_off, c->params + l2.b_off, a_out, y, n,
+                    launch_resblock_bf16(l1.shape, x, c->params + l1.b_off, c->params + l2.b_off, a_out, y, n,
                                          c->banks + l1.bank_f, c->banks + l2.bank_f, c->stream);
                 }
             } else {
@@ -720,6 +721,25 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     for (int b = 2; b >= 0; --b) {
         Block& k = c->blk[b];
         const ConvLayer* L = &c->convs[b * 5];
+        // fused data gradients where they measured faster than two dgrad launches (16 channels @32x32: 14.5 vs 15.9 ms per
+        // iteration; 32 @8x8: equal); at 32 channels @16x16 the two separate launches win (8.3 vs 10.2 ms)
+        if (c->bf && L[1].shape != CS_32_32_16) {
+            // both data gradients of a residual block in one launch (resblock_bf16.hip): the gradient of conv1's output goes
+            // to HBM once (the weight-gradient kernels read it) and to LDS for the second transposed conv
+            const double px = (double)n * L[1].hw * L[1].hw, ch = L[1].cout;
+            auto rb_bwd = [&](const ConvLayer& l1, const ConvLayer& l2, const float* dy, const float* a_fwd, const float* x_fwd, float* da, float* dx) {
+                ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 5, 2.0 * px * 18.0 * ch * ch);
+                launch_resblock_bwd_bf16(l1.shape, dy, a_fwd, x_fwd, da, dx, n, c->banks + l2.bank_d, c->banks + l1.bank_d, c->stream);
+            };
+            // res2: P2 = conv2(relu(A2)) + P1 ; A2 = conv1(relu(P1))
+            rb_bwd(L[3], L[4], Gout, k.A2, k.P1, Ga, Gb);
+            conv_wgrad(c, L[4], k.A2, nullptr, 1, Gout, n);
+            conv_wgrad(c, L[3], k.P1, nullptr, 1, Ga, n);
+            // res1: P1 = conv2(relu(A1)) + P0 ; A1 = conv1(relu(P0))
+            rb_bwd(L[1], L[2], Gb, k.A1, k.P0, Ga, Gout);
+            conv_wgrad(c, L[2], k.A1, nullptr, 1, Gb, n);
+            conv_wgrad(c, L[1], k.P0, nullptr, 1, Ga, n);
+        } else {
         // res2: P2 = conv2(relu(A2)) + P1 ; A2 = conv1(relu(P1))
         conv_wgrad(c, L[4], k.A2, nullptr, 1, Gout, n);
         conv_dgrad(c, L[4], Gout, k.A2, nullptr, Ga, n);
@@ -730,6 +750,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         conv_dgrad(c, L[2], Gb, k.A1, nullptr, Ga, n);
         conv_wgrad(c, L[1], k.P0, nullptr, 1, Ga, n);
         conv_dgrad(c, L[1], Ga, k.P0, Gb, Gout, n);
+        }
         // max pool, then the block's first conv
         if (b == 0 && c->bf) { conv_wgrad(c, L[0], nullptr, &src, 0, Gout, n, k.PI); break; }     // pool backward fused into the staging
         { ProfScope ps(c, PC_POOL_BWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
@@ -1140,6 +1161,48 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
     }
     void* fr[] = {dw, db, din, dres, dmask, ddout, dout_buf};
     for (void* p : fr) if (p) hipFree(p);
+    return 0;
+}
+
+// Fused residual block of the bf16 mode, op level.  mode 0: (x, w1, b1, w2, b2) -> a = conv1(relu(x)) + b1, y = conv2(relu(a)) + b2 + x.
+// mode 1: (dy = x, a_fwd, x_fwd, w1, w2) -> out_a = d a = convT2(dy) * (a_fwd > 0), out_y = d x = convT1(d a) * (x_fwd > 0) + dy.
+int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, const float* x, const float* w1_ref, const float* b1,
+                   const float* w2_ref, const float* b2, const float* a_fwd, const float* x_fwd, float* out_a, float* out_y) {
+    ARG(c && x && w1_ref && w2_ref && out_a && out_y && n >= 1, "null");
+    ARG(c->bf, "the fused residual-block kernels exist in bf16 precision only");
+    ARG(mode == 0 ? (b1 && b2) : (a_fwd && x_fwd), "mode 0 needs the biases, mode 1 the forward tensors");
+    ConvShape s;
+    if (shape_of(ch, ch, hw, &s)) return -1;
+    const size_t X = (size_t)n * hw * hw * ch, wl = (size_t)ch * ch * 9;
+    TensorDesc td{"w", 0, 0, (int64_t)wl, K_CONVW, ch, ch};
+    std::vector<float> wdev(2 * wl + 2 * ch, 0.f);
+    to_device_layout(td, w1_ref, wdev.data()); to_device_layout(td, w2_ref, wdev.data() + wl);
+    if (b1) memcpy(wdev.data() + 2 * wl, b1, ch * 4);
+    if (b2) memcpy(wdev.data() + 2 * wl + ch, b2, ch * 4);
+    float* dparams = nullptr; unsigned short* dbanks = nullptr; BankDesc* ddesc = nullptr;
+    void *dx = nullptr, *da = nullptr, *dxf = nullptr, *doa = nullptr, *doy = nullptr;
+    HIPC(dalloc(&dparams, wdev.size())); HIPC(hipMemcpy(dparams, wdev.data(), wdev.size() * 4, hipMemcpyHostToDevice));
+    const int ws = bank_ws(ch), nk = ch == 32 ? 9 : 5;
+    const long long bl = (long long)ch * ws;
+    // bank 0 feeds the kernel's first conv, bank 1 its second: forward (w1, w2) as stored; backward (w2^T, w1^T)
+    BankDesc d[2] = {{mode ? (long long)wl : 0, 0, ch, ch, ch, ch, mode ? 1 : 0, ws, nk}, {mode ? 0 : (long long)wl, bl, ch, ch, ch, ch, mode ? 1 : 0, ws, nk}};
+    HIPC(dalloc(&dbanks, (size_t)2 * bl)); HIPC(hipMalloc((void**)&ddesc, sizeof d)); HIPC(hipMemcpy(ddesc, d, sizeof d, hipMemcpyHostToDevice));
+    launch_pack_banks(dparams, dbanks, ddesc, 2, c->stream);
+    if (int r = upload_act(c, x, X, &dx)) return r;
+    HIPC(hipMalloc(&doa, X * 2 + 256)); HIPC(hipMalloc(&doy, X * 2 + 256));
+    if (mode == 0) {
+        launch_resblock_bf16(s, dx, dparams + 2 * wl, dparams + 2 * wl + ch, doa, doy, n, dbanks, dbanks + bl, c->stream);
+    } else {
+        if (int r = upload_act(c, a_fwd, X, &da)) return r;
+        if (int r = upload_act(c, x_fwd, X, &dxf)) return r;
+        launch_resblock_bwd_bf16(s, dx, da, dxf, doa, doy, n, dbanks, dbanks + bl, c->stream);
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->stream));
+    if (int r = download_act(c, doa, out_a, X)) return r;
+    if (int r = download_act(c, doy, out_y, X)) return r;
+    void* fr[] = {dparams, dbanks, ddesc, dx, da, dxf, doa, doy};
+    for (void* q : fr) if (q) hipFree(q);
     return 0;
 }
 

@@ -1,97 +1,103 @@
-// Fused residual block forward for the bf16 mode: y = conv2(relu(conv1(relu(x)))) + x   (common/model.py:141-146)
-// in ONE launch per block.  A workgroup owns whole images (the 32x32x16, 16x16x32 and 8x8x32 maps of the IMPALA-CNN
-// all fit in LDS with their zero halo): relu(x) is staged once, conv1's output goes through the epilogue into a
-// second haloed LDS image (ReLU applied), conv2 reads it from there -- the intermediate never makes an HBM round
-// trip inside the forward pass (it is still written once when the backward pass will need it), and the rollout
-// step (n = n_envs, launch-latency bound) runs 6 launches instead of 12 for its residual blocks.
+// Fused residual block for the bf16 mode, ONE launch per block and direction (common/model.py:141-146):
+//   forward   a = conv1(relu(x)) + b1 ;  y = conv2(relu(a)) + b2 + x
+//   backward  da = convT2(dy) * (a > 0) ; dx = convT1(da) * (x > 0) + dy      (the two data gradients)
+// Both are "conv -> elementwise -> conv -> elementwise + skip": the first conv's output goes through its epilogue
+// into a second haloed LDS image and the second conv reads it from there, so the intermediate makes no HBM round
+// trip inside the pass (it is written once: the backward pass / the weight-gradient kernels read it).
+//
+// Work item = TH output rows of one image (or NIMG whole 8x8 images).  For a row tile the first conv is evaluated on
+// TH+2 rows (one halo row each side, recomputed by the neighbour tile) from TH+4 staged input rows; rows outside
+// the image are written as zeros -- they are the second conv's zero padding.  Row tiles keep the LDS footprint at
+// 2-3 workgroups per CU: with whole 32x32 / 16x16 images (85 / 101 KB) a CU held ONE workgroup and every global
+// load of its serial load -> conv -> conv -> store chain was exposed.
+// MFMA operand order as in conv_bf16.hip: filter rows = A, pixels = B, so a lane owns 4 consecutive channels of a
+// pixel and every global / LDS access of the epilogues is an 8-byte word.
 #include "common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ unsigned short rb_f2bf(float x) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
-__device__ __forceinline__ float rb_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned rb_relu2(unsigned w) { const unsigned neg = (w >> 15) & 0x00010001u; return w & ~(neg * 0xFFFFu); }
+__device__ __forceinline__ float rb_lane(uint2 w, int r) {          // bf16 element r (0..3) of an 8-byte word, widened
+    const unsigned u = (r >> 1) ? w.y : w.x;
+    return (r & 1) ? __uint_as_float(u & 0xffff0000u) : __uint_as_float(u << 16);
+}
+__device__ __forceinline__ uint2 rb_pack(const float (&v)[4]) {
+    return (uint2){(unsigned)rb_f2bf(v[0]) | ((unsigned)rb_f2bf(v[1]) << 16), (unsigned)rb_f2bf(v[2]) | ((unsigned)rb_f2bf(v[3]) << 16)};
+}
 
-template <int C_, int HW_, int NIMG_>
+template <int C_, int HW_, int TH_, int NIMG_>
 struct RbCfg {
-    static constexpr int C = C_, HW = HW_, NIMG = NIMG_;
+    static constexpr int C = C_, HW = HW_, TH = TH_, NIMG = NIMG_;
+    static constexpr bool WHOLE = (TH == HW);                // whole images: no halo rows to recompute
+    static_assert(WHOLE || NIMG == 1, "row tiles hold one image");
+    static_assert(HW % TH == 0, "tiles cover the image");
     static constexpr int S = (C == 16) ? 16 : 48;            // conflict-free pixel strides (see conv_bf16.hip)
-    static constexpr int P = HW + 2, NPIX = NIMG * P * P;
-    static constexpr int IMG_ELEMS = ((NPIX * S + 7) / 8) * 8;
+    static constexpr int P = HW + 2;                         // haloed row length
+    static constexpr int R1 = WHOLE ? HW : TH + 2;           // rows the first conv is evaluated on (per image)
+    static constexpr int XR = R1 + 2;                        // staged input rows
+    static constexpr int YR = TH + 2;                        // rows of the intermediate image (conv2's haloed input)
+    static constexpr int X_ELEMS = ((NIMG * XR * P * S + 7) / 8) * 8, Y_ELEMS = ((NIMG * YR * P * S + 7) / 8) * 8;
     static constexpr int NK = (C == 32) ? 9 : 5, WS = NK * 32 + 16, W_ELEMS = C * WS;
-    static constexpr int NMT = NIMG * HW * HW / 16, MT = NMT / 4, NB = C / 16, C8 = C / 8;
-    static constexpr int MTC = MT < 4 ? MT : 4;              // M tiles computed together (bounds the register use)
-    static constexpr int NLD = (NIMG * HW * HW * C8 + 255) / 256;
-    static constexpr size_t LDS_BYTES = (size_t)(2 * IMG_ELEMS + 2 * W_ELEMS) * 2;
-    static_assert(NMT % 4 == 0 && MT % MTC == 0, "tiling");
+    static constexpr int NB = C / 16, C8 = C / 8;
+    static constexpr int NMT1 = NIMG * R1 * HW / 16, NMT2 = NIMG * TH * HW / 16;     // M tiles (16 pixels) of the two convs
+    static constexpr int MT1 = (NMT1 + 3) / 4, MT2 = (NMT2 + 3) / 4;               // per wave (tile t = wave + 4k)
+    static constexpr int pick(int mt) { return mt % 4 == 0 ? 4 : mt % 3 == 0 ? 3 : mt % 2 == 0 ? 2 : 1; }
+    static constexpr int MTC1 = pick(MT1), MTC2 = pick(MT2);   // tiles computed together (bounds the register use)
+    static constexpr int NSRC = NIMG * XR * HW * C8, NLD = (NSRC + 255) / 256;       // 16-byte words staged per item
+    static constexpr int TPI = HW / TH;
+    static constexpr size_t LDS_BYTES = (size_t)(X_ELEMS + Y_ELEMS + 2 * W_ELEMS) * 2;
+    static_assert((NIMG * R1 * HW) % 16 == 0 && (NIMG * TH * HW) % 16 == 0, "whole M tiles");
 };
 
 struct ResblockArgs {
-    const unsigned short* x;      // bf16 NHWC [n][HW][HW][C]
-    const float *w1, *b1, *w2, *b2;   // fp32 device layout [co][tap][ci]
-    unsigned short* a_out;        // conv1 output (pre-ReLU) for the backward pass, or null (rollout)
-    unsigned short* y_out;
+    const unsigned short* x;      // forward: block input; backward: dy          bf16 NHWC [n][HW][HW][C]
+    const float *b1, *b2;         // forward biases (null in the backward instantiation)
+    unsigned short* a_out;        // forward: conv1 output (pre-ReLU) or null (rollout); backward: d(conv1 output)
+    unsigned short* y_out;        // forward: block output; backward: d(block input)
     int n;
-    const unsigned short *bank1, *bank2;   // pre-packed bf16 filter banks (conv_bf16.hip pack_banks_kernel) or null
+    const unsigned short *bank1, *bank2;   // packed bf16 filter banks of the first / second conv of the PASS (conv_bf16.hip pack_banks_kernel)
+    const unsigned short *m1, *m2;         // backward: ReLU mask sources of the first / second conv's output (conv1 forward output, block input)
 };
 
-template <class C>
-__device__ __forceinline__ void rb_stage_weights(unsigned short* s_w, const float* w) {
-    for (int e = threadIdx.x; e < C::C * C::WS; e += 256) {
-        const int j = e / C::WS, k = e % C::WS, tap = k / C::C, ci = k % C::C;
-        s_w[e] = rb_f2bf((k < C::NK * 32 && tap < 9) ? w[(j * 9 + tap) * C::C + ci] : 0.f);
-    }
-}
-
-// one 3x3 conv over the haloed LDS image s_src for MTC consecutive M tiles starting at mt0
-template <class C>
-__device__ __forceinline__ void rb_conv(const unsigned short* s_src, const unsigned short* s_w, const int (&koff)[C::NK], int mt0, int wave,
-                                        int i, int kq, f32x4 (&acc)[C::MTC][C::NB]) {
+// one 3x3 conv over a haloed LDS image for up to MTC M tiles (pixel tiles whose LDS base offsets are given)
+template <class C, int MTC>
+__device__ __forceinline__ void rb_conv(const unsigned short* s_src, const unsigned short* s_w, const int (&koff)[C::NK], const int (&abase)[MTC],
+                                        int i, int kq, f32x4 (&acc)[MTC][C::NB]) {
 #pragma unroll
-    for (int mt = 0; mt < C::MTC; ++mt)
+    for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
         for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int abase[C::MTC];
-#pragma unroll
-    for (int mt = 0; mt < C::MTC; ++mt) {
-        const int pl = (wave * C::MT + mt0 + mt) * 16 + i, y = pl / C::HW, x = pl % C::HW;
-        abase[mt] = (((y / C::HW) * C::P + (y % C::HW)) * C::P + x) * C::S;
-    }
     const int bbase = i * C::WS + kq * 8;
 #pragma unroll
     for (int m = 0; m < C::NK; ++m) {
-        bf16x8 av[C::MTC], bv[C::NB];
+        bf16x8 av[MTC], bv[C::NB];
 #pragma unroll
-        for (int mt = 0; mt < C::MTC; ++mt) av[mt] = *(const bf16x8*)(s_src + abase[mt] + koff[m]);
+        for (int mt = 0; mt < MTC; ++mt) av[mt] = *(const bf16x8*)(s_src + abase[mt] + koff[m]);
 #pragma unroll
         for (int nb = 0; nb < C::NB; ++nb) bv[nb] = *(const bf16x8*)(s_w + bbase + nb * 16 * C::WS + m * 32);
 #pragma unroll
-        for (int mt = 0; mt < C::MTC; ++mt)
+        for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
-            for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);      // filters as A: 4 channels of one pixel per lane
+            for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);
     }
 }
 
-template <class C>
+template <class C, bool BWD>
 __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
-    unsigned short* s_x = smem_h;                         // relu(x), haloed
-    unsigned short* s_y = smem_h + C::IMG_ELEMS;          // relu(conv1 output), haloed
-    unsigned short* s_w1 = smem_h + 2 * C::IMG_ELEMS;
+    unsigned short* s_x = smem_h;                         // staged input (ReLU applied in the forward pass), haloed
+    unsigned short* s_y = smem_h + C::X_ELEMS;            // first conv's output after its epilogue, haloed
+    unsigned short* s_w1 = s_y + C::Y_ELEMS;
     unsigned short* s_w2 = s_w1 + C::W_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
-    if (a.bank1 && a.bank2) {
-        for (int e = tid; e < C::W_ELEMS / 8; e += 256) { ((uint4*)s_w1)[e] = ((const uint4*)a.bank1)[e]; ((uint4*)s_w2)[e] = ((const uint4*)a.bank2)[e]; }
-    } else {
-        rb_stage_weights<C>(s_w1, a.w1);
-        rb_stage_weights<C>(s_w2, a.w2);
-    }
-    for (int e = tid; e < 2 * C::IMG_ELEMS / 8; e += 256) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // zero halos (interiors are rewritten)
+    for (int e = tid; e < C::W_ELEMS / 8; e += 256) { ((uint4*)s_w1)[e] = ((const uint4*)a.bank1)[e]; ((uint4*)s_w2)[e] = ((const uint4*)a.bank2)[e]; }
+    for (int e = tid; e < (C::X_ELEMS + C::Y_ELEMS) / 8; e += 256) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
     float b1r[C::NB][4], b2r[C::NB][4];                   // channels nb*16 + 4*kq + r: the accumulator quad of this lane
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { b1r[nb][r] = a.b1[nb * 16 + kq * 4 + r]; b2r[nb][r] = a.b2[nb * 16 + kq * 4 + r]; }
+        for (int r = 0; r < 4; ++r) { b1r[nb][r] = BWD ? 0.f : a.b1[nb * 16 + kq * 4 + r]; b2r[nb][r] = BWD ? 0.f : a.b2[nb * 16 + kq * 4 + r]; }
     int koff[C::NK];
 #pragma unroll
     for (int m = 0; m < C::NK; ++m) {
@@ -99,116 +105,181 @@ __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
         if (C::C == 32) { tap = m; chunk = kq; } else { tap = 2 * m + (kq >> 1); chunk = kq & 1; if (tap > 8) tap = 8; }
         koff[m] = ((tap / 3) * C::P + (tap % 3)) * C::S + chunk * 8;
     }
-    const int nwork = (a.n + C::NIMG - 1) / C::NIMG;
+    const int nwork = C::WHOLE ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
+    auto item = [&](int work, int& img0, int& ty0) {
+        if (C::WHOLE) { img0 = work * C::NIMG; ty0 = 0; } else { img0 = work / C::TPI; ty0 = (work % C::TPI) * C::TH; }
+    };
+    // staged row r of image slot `img` is image row gy0 + r
     uint4 regs[C::NLD];
-    auto load = [&](int img0) {
+    auto load = [&](int img0, int ty0) {
+        const int gy0 = C::WHOLE ? -1 : ty0 - 2;
 #pragma unroll
         for (int k = 0; k < C::NLD; ++k) {
             const int e = tid + k * 256;
             uint4 v = {0u, 0u, 0u, 0u};
-            if (e < C::NIMG * C::HW * C::HW * C::C8) {
-                const int pix = e / C::C8, c8 = e % C::C8, n = img0 + pix / (C::HW * C::HW);
-                if (n < a.n) v = *(const uint4*)(a.x + ((long long)img0 * C::HW * C::HW + pix) * C::C + c8 * 8);
+            if (e < C::NSRC) {
+                const int c8 = e % C::C8, px = (e / C::C8) % C::HW, r = (e / (C::C8 * C::HW)) % C::XR, img = e / (C::C8 * C::HW * C::XR);
+                const int gy = gy0 + r, n = img0 + img;
+                if (n < a.n && gy >= 0 && gy < C::HW) v = *(const uint4*)(a.x + (((long long)n * C::HW + gy) * C::HW + px) * C::C + c8 * 8);
             }
             regs[k] = v;
         }
     };
-    if ((int)blockIdx.x < nwork) load(blockIdx.x * C::NIMG);
+    int img0, ty0;
+    if ((int)blockIdx.x < nwork) { item(blockIdx.x, img0, ty0); load(img0, ty0); }
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
-        const int img0 = work * C::NIMG;
+        item(work, img0, ty0);
         __syncthreads();                                   // previous item's LDS reads done (and the zero fill, first time)
 #pragma unroll
         for (int k = 0; k < C::NLD; ++k) {
             const int e = tid + k * 256;
-            if (e < C::NIMG * C::HW * C::HW * C::C8) {
-                const int pix = e / C::C8, c8 = e % C::C8, img = pix / (C::HW * C::HW), q = pix % (C::HW * C::HW);
+            if (e < C::NSRC) {
+                const int c8 = e % C::C8, px = (e / C::C8) % C::HW, rr = e / (C::C8 * C::HW);      // rr = img * XR + r
                 uint4 v = regs[k];
-                v.x = rb_relu2(v.x); v.y = rb_relu2(v.y); v.z = rb_relu2(v.z); v.w = rb_relu2(v.w);
-                *(uint4*)(s_x + ((img * C::P + q / C::HW + 1) * C::P + q % C::HW + 1) * C::S + c8 * 8) = v;
+                if (!BWD) { v.x = rb_relu2(v.x); v.y = rb_relu2(v.y); v.z = rb_relu2(v.z); v.w = rb_relu2(v.w); }
+                *(uint4*)(s_x + (rr * C::P + px + 1) * C::S + c8 * 8) = v;
             }
         }
         __syncthreads();
-        if (work + (int)gridDim.x < nwork) load((work + gridDim.x) * C::NIMG);
+        if (work + (int)gridDim.x < nwork) { int i2, y2; item(work + gridDim.x, i2, y2); load(i2, y2); }
 
-        // ---- conv1 -> a (HBM, optional) and relu(a) -> s_y
+        // ---- first conv: rows gy1 + ry (ry < R1) -> global (owned rows only) and the intermediate LDS image
+        const int gy1 = C::WHOLE ? 0 : ty0 - 1;
 #pragma unroll 1
-        for (int mt0 = 0; mt0 < C::MT; mt0 += C::MTC) {
-            f32x4 acc[C::MTC][C::NB];
-            rb_conv<C>(s_x, s_w1, koff, mt0, wave, i, kq, acc);
+        for (int k0 = 0; k0 < C::MT1; k0 += C::MTC1) {
+            int abase[C::MTC1], ybase[C::MTC1];
+            long long goff[C::MTC1];
+            bool inimg[C::MTC1], owned[C::MTC1];
 #pragma unroll
-            for (int mt = 0; mt < C::MTC; ++mt) {
-                const int pl = (wave * C::MT + mt0 + mt) * 16 + i, y = pl / C::HW, x = pl % C::HW, img = y / C::HW, n = img0 + img;
+            for (int mt = 0; mt < C::MTC1; ++mt) {
+                int t = wave + 4 * (k0 + mt);
+                const bool live = t < C::NMT1;
+                t = live ? t : C::NMT1 - 1;
+                const int pl = t * 16 + i, px = pl % C::HW, ry = (pl / C::HW) % C::R1, img = pl / (C::HW * C::R1);
+                const int gy = gy1 + ry, n = img0 + img;
+                abase[mt] = ((img * C::XR + ry) * C::P + px) * C::S;
+                ybase[mt] = ((img * C::YR + ry + (C::WHOLE ? 1 : 0)) * C::P + px + 1) * C::S + kq * 4;
+                inimg[mt] = live && gy >= 0 && gy < C::HW && n < a.n;
+                owned[mt] = inimg[mt] && (C::WHOLE || (ry >= 1 && ry <= C::TH));
+                goff[mt] = inimg[mt] ? (((long long)n * C::HW + gy) * C::HW + px) * C::C + kq * 4 : (long long)kq * 4;
+                if (!live) ybase[mt] = -1;
+            }
+            uint2 e_m[C::MTC1][C::NB];                       // backward: mask source, requested before the MFMAs
+            if (BWD) {
+#pragma unroll
+                for (int mt = 0; mt < C::MTC1; ++mt)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) e_m[mt][nb] = *(const uint2*)(a.m1 + goff[mt] + nb * 16);
+            }
+            f32x4 acc[C::MTC1][C::NB];
+            rb_conv<C, C::MTC1>(s_x, s_w1, koff, abase, i, kq, acc);
+#pragma unroll
+            for (int mt = 0; mt < C::MTC1; ++mt) {
+                if (ybase[mt] < 0) continue;
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb) {
-                    unsigned short h[4];
+                    float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h[r] = rb_f2bf(acc[mt][nb][r] + b1r[nb][r]);
-                    const uint2 raw = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
-                    if (a.a_out && n < a.n) *(uint2*)(a.a_out + ((long long)img0 * C::HW * C::HW + pl) * C::C + nb * 16 + kq * 4) = raw;
-                    *(uint2*)(s_y + ((img * C::P + (y % C::HW) + 1) * C::P + x + 1) * C::S + nb * 16 + kq * 4) = (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[mt][nb][r] + b1r[nb][r];
+                        if (BWD) v[r] = rb_lane(e_m[mt][nb], r) > 0.f ? v[r] : 0.f;
+                    }
+                    uint2 raw = rb_pack(v);
+                    if (!inimg[mt]) raw = (uint2){0u, 0u};                          // outside the image: the second conv's zero padding
+                    if (a.a_out && owned[mt]) *(uint2*)(a.a_out + goff[mt] + nb * 16) = raw;
+                    *(uint2*)(s_y + ybase[mt] + nb * 16) = BWD ? raw : (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};
                 }
             }
         }
         __syncthreads();
-        // ---- conv2 + residual -> y
+        // ---- second conv + skip connection: rows ty0 + oy (oy < TH)
 #pragma unroll 1
-        for (int mt0 = 0; mt0 < C::MT; mt0 += C::MTC) {
-            uint2 e_res[C::MTC][C::NB];
+        for (int k0 = 0; k0 < C::MT2; k0 += C::MTC2) {
+            int abase[C::MTC2];
+            long long goff[C::MTC2];
+            bool on[C::MTC2];
 #pragma unroll
-            for (int mt = 0; mt < C::MTC; ++mt) {
-                const int pl = (wave * C::MT + mt0 + mt) * 16 + i;
-                const int n = img0 + pl / (C::HW * C::HW);
-                const long long o = ((long long)(n < a.n ? img0 : 0) * C::HW * C::HW + (n < a.n ? pl : 0)) * C::C + kq * 4;
-#pragma unroll
-                for (int nb = 0; nb < C::NB; ++nb) e_res[mt][nb] = *(const uint2*)(a.x + o + nb * 16);        // raw x (L2-resident: just staged)
+            for (int mt = 0; mt < C::MTC2; ++mt) {
+                int t = wave + 4 * (k0 + mt);
+                const bool live = t < C::NMT2;
+                t = live ? t : C::NMT2 - 1;
+                const int pl = t * 16 + i, px = pl % C::HW, oy = (pl / C::HW) % C::TH, img = pl / (C::HW * C::TH);
+                const int n = img0 + img;
+                abase[mt] = ((img * C::YR + oy) * C::P + px) * C::S;
+                on[mt] = live && n < a.n;
+                goff[mt] = on[mt] ? (((long long)n * C::HW + ty0 + oy) * C::HW + px) * C::C + kq * 4 : (long long)kq * 4;
             }
-            f32x4 acc[C::MTC][C::NB];
-            rb_conv<C>(s_y, s_w2, koff, mt0, wave, i, kq, acc);
+            uint2 e_res[C::MTC2][C::NB], e_m[C::MTC2][C::NB];
 #pragma unroll
-            for (int mt = 0; mt < C::MTC; ++mt) {
-                const int pl = (wave * C::MT + mt0 + mt) * 16 + i, n = img0 + pl / (C::HW * C::HW);
-                if (n < a.n) {
+            for (int mt = 0; mt < C::MTC2; ++mt)
 #pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) {
-                        const unsigned rw[2] = {e_res[mt][nb].x, e_res[mt][nb].y};
-                        unsigned short h[4];
+                for (int nb = 0; nb < C::NB; ++nb) {
+                    e_res[mt][nb] = *(const uint2*)(a.x + goff[mt] + nb * 16);          // raw x / dy (L2-resident: just staged)
+                    if (BWD) e_m[mt][nb] = *(const uint2*)(a.m2 + goff[mt] + nb * 16);
+                }
+            f32x4 acc[C::MTC2][C::NB];
+            rb_conv<C, C::MTC2>(s_y, s_w2, koff, abase, i, kq, acc);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float rs = (r & 1) ? __uint_as_float(rw[r >> 1] & 0xffff0000u) : __uint_as_float(rw[r >> 1] << 16);
-                            h[r] = rb_f2bf(acc[mt][nb][r] + b2r[nb][r] + rs);
-                        }
-                        *(uint2*)(a.y_out + ((long long)img0 * C::HW * C::HW + pl) * C::C + nb * 16 + kq * 4) =
-                            (uint2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+            for (int mt = 0; mt < C::MTC2; ++mt) {
+                if (!on[mt]) continue;
+#pragma unroll
+                for (int nb = 0; nb < C::NB; ++nb) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[mt][nb][r] + b2r[nb][r];
+                        if (BWD) v[r] = rb_lane(e_m[mt][nb], r) > 0.f ? v[r] : 0.f;
+                        v[r] += rb_lane(e_res[mt][nb], r);
                     }
+                    *(uint2*)(a.y_out + goff[mt] + nb * 16) = rb_pack(v);
                 }
             }
         }
     }
 }
 
-using RB_16_32 = RbCfg<16, 32, 1>;
-using RB_32_16 = RbCfg<32, 16, 1>;
-using RB_32_8  = RbCfg<32,  8, 4>;
+//                      C  HW  TH NIMG
+using RB_16_32 = RbCfg<16, 32, 16, 1>;      // 53 KB LDS: 3 workgroups per CU
+using RB_32_16 = RbCfg<32, 16, 16, 1>;      // whole image, 101 KB: 1 per CU -- measured faster than 8-row tiles (77 KB, 2 per CU,
+                                            // 25 % halo recompute): 6.3 vs 7.7 ms per iteration forward
+using RB_32_8  = RbCfg<32,  8,  8, 2>;      // 70 KB: 2 per CU
+using RB_32_8S = RbCfg<32,  8,  8, 1>;      // rollout-sized batches: one image per workgroup (more workgroups, less serial work each)
 
-template <class C>
+template <class C, bool BWD = false>
 static void launch_rb_t(const ResblockArgs& a, hipStream_t st) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)resblock_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    if (!attr) { hipFuncSetAttribute((const void*)resblock_bf16_kernel<C, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
     int bpc = (int)((160 * 1024) / C::LDS_BYTES);
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
-    int grid = (a.n + C::NIMG - 1) / C::NIMG;
+    int grid = C::WHOLE ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
     if (grid > 256 * bpc) grid = 256 * bpc;
     if (grid < 1) return;
-    hipLaunchKernelGGL(resblock_bf16_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((resblock_bf16_kernel<C, BWD>), dim3(grid), dim3(256), C::LDS_BYTES, st, a);
 }
-// shape = the residual convs' ConvShape (CS_16_16_32 / CS_32_32_16 / CS_32_32_8)
-void launch_resblock_bf16(ConvShape s, const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* a_out,
-                          void* y_out, int n, const unsigned short* bank1, const unsigned short* bank2, hipStream_t st) {
-    ResblockArgs a{(const unsigned short*)x, w1, b1, w2, b2, (unsigned short*)a_out, (unsigned short*)y_out, n, bank1, bank2};
+// shape = the residual convs' ConvShape (CS_16_16_32 / CS_32_32_16 / CS_32_32_8); bank1 / bank2 = forward banks of conv1 / conv2
+void launch_resblock_bf16(ConvShape s, const void* x, const float* b1, const float* b2, void* a_out, void* y_out, int n,
+                          const unsigned short* bank1, const unsigned short* bank2, hipStream_t st) {
+    ResblockArgs a{(const unsigned short*)x, b1, b2, (unsigned short*)a_out, (unsigned short*)y_out, n, bank1, bank2, nullptr, nullptr};
     switch (s) {
         case CS_16_16_32: launch_rb_t<RB_16_32>(a, st); break;
         case CS_32_32_16: launch_rb_t<RB_32_16>(a, st); break;
-        case CS_32_32_8:  launch_rb_t<RB_32_8>(a, st); break;
+        case CS_32_32_8:  if (n <= 1024) launch_rb_t<RB_32_8S>(a, st); else launch_rb_t<RB_32_8>(a, st); break;
+        default: break;
+    }
+}
+
+// Data gradients of a residual block in one launch:
+//   dA = convT2(dy) * (A > 0)      -> da_out        (A = conv1's forward output; the weight-gradient kernels read dA)
+//   dx = convT1(dA) * (x > 0) + dy -> dx_out        (x = the block input)
+// bank2_t / bank1_t: the transposed ("dgrad") filter banks of conv2 / conv1.
+void launch_resblock_bwd_bf16(ConvShape s, const void* dy, const void* a_fwd, const void* x_fwd, void* da_out, void* dx_out, int n,
+                              const unsigned short* bank2_t, const unsigned short* bank1_t, hipStream_t st) {
+    ResblockArgs a{(const unsigned short*)dy, nullptr, nullptr, (unsigned short*)da_out, (unsigned short*)dx_out, n,
+                   bank2_t, bank1_t, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd};
+    switch (s) {
+        case CS_16_16_32: launch_rb_t<RB_16_32, true>(a, st); break;
+        case CS_32_32_16: launch_rb_t<RB_32_16, true>(a, st); break;
+        case CS_32_32_8:  launch_rb_t<RB_32_8, true>(a, st); break;
         default: break;
     }
 }

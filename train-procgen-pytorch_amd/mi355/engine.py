@@ -41,7 +41,7 @@ EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_fre
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
            "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_predict_staged mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_optimizer_step mi_loss_log_read mi_device_ptr "
-           "mi_set_multirank mi_minibatch_finish mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
+           "mi_set_multirank mi_minibatch_finish mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
 
 
 def load_library():
@@ -328,6 +328,17 @@ class Engine:
                                          C.c_int32(n), _fp(inp), C.c_int32(int(is_u8)), C.c_int32(int(relu_in)), _fp(w_ref),
                                          _fp(bias), _fp(res), _fp(mask), _fp(dout), _fp(out), _fp(db)))
         return (out, db) if mode in (2, 4) else out
+
+    def op_resblock(self, mode, x, w1, w2, b1=None, b2=None, a_fwd=None, x_fwd=None):
+        """bf16 precision: fused residual block.  mode 0 -> (conv1 output, block output); mode 1 (x = dy) -> (d conv1-output, d block-input)."""
+        x = _f32(x)
+        n, hw, _, ch = x.shape
+        w1, w2 = _f32(w1), _f32(w2)
+        b1, b2, a_fwd, x_fwd = (None if a is None else _f32(a) for a in (b1, b2, a_fwd, x_fwd))
+        oa, oy = np.empty_like(x), np.empty_like(x)
+        self._chk(self.lib.mi_op_resblock(self._ctx, C.c_int32(mode), C.c_int32(ch), C.c_int32(hw), C.c_int32(n), _fp(x), _fp(w1), _fp(b1),
+                                          _fp(w2), _fp(b2), _fp(a_fwd), _fp(x_fwd), _fp(oa), _fp(oy)))
+        return oa, oy
 
     def op_maxpool(self, mode, x, dout=None):
         x = _f32(x)
