@@ -110,6 +110,32 @@ def test_block1_conv_pool_fused_bf16(eng, n):
     assert relerr(gb, dc.sum(dim=(0, 2, 3)).numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,hw", [(16, 32, 32), (32, 32, 16)])
+@pytest.mark.parametrize("n", [1, 5])
+def test_block_conv_pool_fused_bf16(eng, cin, cout, hw, n):
+    """block2.conv / block3.conv + MaxPool2d(3,2,1) in one launch, and both gradients of the conv taken from the POOLED
+    gradient + arg-max bytes (max-pool backward fused into the operand staging of the weight- and data-gradient
+    kernels).  Forward oracle: the unfused kernels (bit-identical: same conv arithmetic, same tie rule).  Backward
+    oracle: torch autograd through max_pool2d on the kernel's own bf16 conv output."""
+    w, b, x_dev, x = _inputs(cin, cout, hw, n, 21)
+    conv = eng.op_conv3x3(0, cin, cout, hw, w.numpy(), inp=x_dev, bias=b.numpy())
+    pooled = eng.op_conv3x3(3, cin, cout, hw, w.numpy(), inp=x_dev, bias=b.numpy())
+    assert np.array_equal(pooled, eng.op_maxpool(0, conv))
+    c = torch.from_numpy(conv).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = F.max_pool2d(c, kernel_size=3, stride=2, padding=1)
+    assert np.array_equal(pooled, nhwc(y.detach()))
+    dy = r16(torch.randn(y.shape, generator=torch.Generator().manual_seed(22)))
+    y.backward(dy)
+    dc = r16(c.grad)                                                    # the staging rounds the gathered sum to bf16
+    ref_w = torch.nn.grad.conv2d_weight(x, w.shape, dc, padding=1)
+    gw, gb = eng.op_conv3x3(4, cin, cout, hw, w.numpy(), inp=x_dev, bias=b.numpy(), dout=nhwc(dy))
+    assert relerr(gw, ref_w.numpy()) < 1e-4
+    assert relerr(gb, dc.sum(dim=(0, 2, 3)).numpy()) < 1e-4
+    ref_x = torch.nn.grad.conv2d_input(x.shape, r16(w), dc, padding=1)
+    gx = eng.op_conv3x3(5, cin, cout, hw, w.numpy(), inp=x_dev, bias=b.numpy(), dout=nhwc(dy))
+    assert relerr(gx, nhwc(ref_x)) < 1e-2
+
+
 @pytest.mark.parametrize("ch,hw", [(16, 32), (32, 16), (32, 8)])
 @pytest.mark.parametrize("n", [1, 6])
 def test_fused_residual_block_bf16(eng, ch, hw, n):

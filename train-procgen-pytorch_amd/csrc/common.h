@@ -26,6 +26,8 @@ struct ConvArgs {
     int            bf16;      // activations (in/res/mask/out) are bf16 in HBM
     const unsigned short* wbank;   // bf16 mode: pre-packed filter bank in the kernel's LDS layout (conv_bf16.hip), or null
     const unsigned short* lut16;   // bf16 mode: 256-entry uint8 -> bf16 table (block1.conv)
+    const uint8_t* pool_arg;       // bf16 data gradient of a block's first conv: `in` is the POOLED gradient [n][HW/2][HW/2][C] and these
+                                   // are the max-pool arg-max bytes; the conv-output gradient is rebuilt in LDS (pool backward fused)
 };
 
 struct WgradArgs {
@@ -143,6 +145,7 @@ void launch_fc_dgrad_bf16(const float* dy, const unsigned short* wt, const void*
 void launch_fc_tn(const float* A, const unsigned short* B, float* gW, float* ws, size_t ws_floats, int M, int N, int K, hipStream_t st);
 
 // fused residual block forward, bf16 mode (resblock_bf16.hip); s = ConvShape of the block's convs
+bool launch_conv_pool_fwd_bf16(ConvShape s, const ConvArgs& a, void* p_out, uint8_t* p_arg, hipStream_t st);
 void launch_resblock_bf16(ConvShape s, const void* x, const float* b1, const float* b2, void* a_out, void* y_out, int n,
                           const unsigned short* bank1, const unsigned short* bank2, hipStream_t st);
 void launch_resblock_bwd_bf16(ConvShape s, const void* dy, const void* a_fwd, const void* x_fwd, void* da_out, void* dx_out, int n,

@@ -20,6 +20,92 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
+// ------------------------------------------------------------------------------------------ max-pool backward as an operand stage
+// The gradient of a block's first conv output is never stored: its consumers (the conv's data-gradient and weight-gradient
+// kernels) rebuild the window they need in LDS from the POOLED gradient and the arg-max bytes MaxPool2d(3,2,1) left.
+// Staged: NPR pooled rows (first = oyb) x HO cols x CH channels, gradient as bf16 + arg-max as bytes; rows outside the
+// pooled map carry arg 0xff (matches no position).  A thread then owns a 2x2 block of conv pixels x 4 channels: the 4
+// windows (oy, ox) in {a, a+1} x {b, b+1} touching the block are read once each, their 9 (window, pixel) incidences -- one
+// per pool position -- use compile-time (ky, kx); windows are added in (oy, ox) order, the order of the stand-alone kernel.
+// Conv rows outside the image come out as zeros by themselves (no window's arg-max points outside the image).
+template <int CH, int HO, int NPR>
+struct PoolStage {
+    static constexpr int NW = NPR * HO * (CH / 8), K = (NW + 255) / 256;      // 16-byte gradient words (+ 8-byte arg words) per item
+    static constexpr int PD_ELEMS = NPR * HO * CH;                          // bf16 elements; the arg bytes follow
+    static constexpr size_t BYTES = (size_t)PD_ELEMS * 3;
+    uint4 rd[K]; uint2 ra[K];
+    __device__ __forceinline__ void load(const unsigned short* g_dp, const uint8_t* g_arg, long long img, int oyb) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = threadIdx.x + k * 256;
+            rd[k] = (uint4){0u, 0u, 0u, 0u}; ra[k] = (uint2){0xffffffffu, 0xffffffffu};
+            if (e < NW) {
+                const int c8 = e % (CH / 8), ox = (e / (CH / 8)) % HO, oy = oyb + e / ((CH / 8) * HO);
+                if (oy >= 0 && oy < HO) {
+                    const long long o = ((img * HO + oy) * HO + ox) * CH + c8 * 8;
+                    rd[k] = *(const uint4*)(g_dp + o); ra[k] = *(const uint2*)(g_arg + o);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short* s_pd) const {
+        uint8_t* s_pa = (uint8_t*)(s_pd + PD_ELEMS);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = threadIdx.x + k * 256;
+            if (e < NW) { *(uint4*)(s_pd + e * 8) = rd[k]; *(uint2*)(s_pa + e * 8) = ra[k]; }
+        }
+    }
+    // block rows a0 .. a0+NPR-2 (staged pooled row 0 = a0); writes conv rows y in [y_lo, y_hi) to
+    // s_dst[((y - y_base) * dst_pw + x + xoff) * S + channel]
+    static __device__ __forceinline__ void gather(const unsigned short* s_pd, int a0, int y_lo, int y_hi, unsigned short* s_dst, int y_base,
+                                                  int dst_pw, int xoff, int S) {
+        const uint8_t* s_pa = (const uint8_t*)(s_pd + PD_ELEMS);
+        constexpr int Q = CH / 4;
+        for (int task = threadIdx.x; task < (NPR - 1) * HO * Q; task += 256) {
+            const int cq = task % Q, bx = (task / Q) % HO, bl = task / (Q * HO);
+            float sm[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sm[q][c] = 0.f;
+#pragma unroll
+            for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+                for (int wx = 0; wx < 2; ++wx) {
+                    const int ox = bx + wx;
+                    const int o = ((bl + wy) * HO + (ox < HO ? ox : HO - 1)) * CH + cq * 4;
+                    const uint2 d = *(const uint2*)(s_pd + o);
+                    unsigned ag = *(const unsigned*)(s_pa + o);
+                    if (ox >= HO) ag = 0xffffffffu;                            // window column HO does not exist
+                    const float v[4] = {__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u), __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u)};
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int ky = dy + 1 - 2 * wy, kx = dx + 1 - 2 * wx;
+                            if (ky < 0 || kx < 0) continue;
+                            const unsigned pos = (unsigned)(ky * 3 + kx);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (((ag >> (8 * c)) & 0xffu) == pos) sm[dy * 2 + dx][c] += v[c];
+                        }
+                }
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int y = 2 * (a0 + bl) + dy;
+                if (y < y_lo || y >= y_hi) continue;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float* q = sm[dy * 2 + dx];
+                    *(uint2*)(s_dst + ((y - y_base) * dst_pw + 2 * bx + dx + xoff) * S + cq * 4) =
+                        (uint2){(unsigned)f2bf(q[0]) | ((unsigned)f2bf(q[1]) << 16), (unsigned)f2bf(q[2]) | ((unsigned)f2bf(q[3]) << 16)};
+                }
+            }
+        }
+    }
+};
+
 template <int CIN_, int COUT_, int HW_, int TH_, int TW_, int NIMG_, bool TRANSW_>
 struct BfCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, HW = HW_, TH = TH_, TW = TW_, NIMG = NIMG_;
@@ -80,11 +166,16 @@ __device__ __forceinline__ void bf_tile_store(const uint4 (&r)[C::NLD], unsigned
     }
 }
 
-template <class C>
+// POOLIN (data gradient of a block's first conv): a.in is the POOLED gradient, a.pool_arg the arg-max bytes; the haloed
+// tile of the conv-output gradient is rebuilt in LDS by PoolStage::gather instead of being loaded.
+template <class C, bool POOLIN = false>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_in = smem_h;
     unsigned short* s_w = smem_h + C::IN_ELEMS;
+    using PS = PoolStage<C::CIN, C::HW / 2, C::TH / 2 + 3>;                // pooled rows ty0/2 - 1 .. ty0/2 + TH/2 + 1
+    unsigned short* s_pd = s_w + C::W_ELEMS;
+    static_assert(!POOLIN || (C::NIMG == 1 && C::TW == C::HW && C::TH % 2 == 0), "pooled input: full-width row tiles of one image");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const unsigned short* g_in = (const unsigned short*)a.in;
@@ -124,18 +215,27 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a) {
     }
 
     const int nwork = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
-    uint4 regs[C::NLD];
+    uint4 regs[POOLIN ? 1 : C::NLD];
+    PS ps;
     int img0, ty0, tx0;
-    if ((int)blockIdx.x < nwork) { bf_coords<C>(blockIdx.x, img0, ty0, tx0); bf_tile_load<C>(regs, g_in, a.n, img0, ty0, tx0); }
+    if (POOLIN) for (int e = tid; e < C::IN_ELEMS / 8; e += 256) ((uint4*)s_in)[e] = (uint4){0u, 0u, 0u, 0u};      // halo columns stay zero
+    if ((int)blockIdx.x < nwork) {
+        bf_coords<C>(blockIdx.x, img0, ty0, tx0);
+        if constexpr (POOLIN) ps.load(g_in, a.pool_arg, img0, ty0 / 2 - 1); else bf_tile_load<C>(regs, g_in, a.n, img0, ty0, tx0);
+    }
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         bf_coords<C>(work, img0, ty0, tx0);
         __syncthreads();
-        bf_tile_store<C>(regs, s_in, a.relu_in);
+        if constexpr (POOLIN) {
+            ps.store(s_pd);
+            __syncthreads();
+            PS::gather(s_pd, ty0 / 2 - 1, ty0 - 1, ty0 + C::TH + 1, s_in, ty0 - 1, C::PW, 1, C::S);
+        } else bf_tile_store<C>(regs, s_in, a.relu_in);
         __syncthreads();
         if (work + (int)gridDim.x < nwork) {
             int i2, y2, x2;
             bf_coords<C>(work + gridDim.x, i2, y2, x2);
-            bf_tile_load<C>(regs, g_in, a.n, i2, y2, x2);
+            if constexpr (POOLIN) ps.load(g_in, a.pool_arg, i2, y2 / 2 - 1); else bf_tile_load<C>(regs, g_in, a.n, i2, y2, x2);
         }
         // epilogue operands requested before the MFMA phase (one wave-uniform branch per block of loads)
         uint2 e_mask[C::MT][C::NB], e_res[C::MT][C::NB];
@@ -286,9 +386,14 @@ __device__ unsigned long long g_wg_timing[8];
 #define TCK(k) do { } while (0)
 #endif
 
-template <class C>
+// POOLED (a block's first conv): a.dout is the POOLED gradient, a.pool_arg the arg-max bytes; the dOut tile is rebuilt in
+// LDS by PoolStage::gather (max-pool backward fused into the operand staging).
+template <class C, bool POOLED = false>
 __global__ __launch_bounds__(256, C::SPLIT ? WG_WPE : 1) void conv3x3_wgrad_bf16_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    using PS = PoolStage<C::COUT, C::HW / 2, C::TH / 2 + 1>;              // pooled rows ty0/2 .. ty0/2 + TH/2
+    static_assert(!POOLED || (C::NIMG == 1 && C::TW == C::HW && C::TH % 2 == 0), "pooled dOut: full-width row tiles of one image");
+    PS ps;
 #ifdef WG_TIMING
     long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
 #endif
@@ -350,11 +455,14 @@ __global__ __launch_bounds__(256, C::SPLIT ? WG_WPE : 1) void conv3x3_wgrad_bf16
                 if (ioff[k] >= 0 && (C::NIMG == 1 || ioff[k] / (C::HW * C::HW * C::CIN) < left)) v = *(const uint4*)(bi + ioff[k]);
                 rin[k] = v;
             }
+            if constexpr (POOLED) ps.load(g_do, a.pool_arg, img0, ty0 / 2);
+            else {
 #pragma unroll
-            for (int k = 0; k < C::NDO; ++k) {
-                uint4 v = {0u, 0u, 0u, 0u};
-                if (doff[k] >= 0 && (C::NIMG == 1 || doff[k] / (C::HW * C::HW * C::COUT) < left)) v = *(const uint4*)(bd + doff[k]);
-                rdo[k] = v;
+                for (int k = 0; k < C::NDO; ++k) {
+                    uint4 v = {0u, 0u, 0u, 0u};
+                    if (doff[k] >= 0 && (C::NIMG == 1 || doff[k] / (C::HW * C::HW * C::COUT) < left)) v = *(const uint4*)(bd + doff[k]);
+                    rdo[k] = v;
+                }
             }
             return;
         }
@@ -370,6 +478,7 @@ __global__ __launch_bounds__(256, C::SPLIT ? WG_WPE : 1) void conv3x3_wgrad_bf16
             }
             rin[k] = v;
         }
+        if constexpr (POOLED) { ps.load(g_do, a.pool_arg, img0, ty0 / 2); return; }
 #pragma unroll
         for (int k = 0; k < C::NDO; ++k) {
             const int e = tid + k * 256;
@@ -388,6 +497,8 @@ __global__ __launch_bounds__(256, C::SPLIT ? WG_WPE : 1) void conv3x3_wgrad_bf16
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         __syncthreads();
         TCK(1);
+        int ty_cur = 0;
+        if constexpr (POOLED) { int i_, x_; coords(work, i_, ty_cur, x_); }
 #pragma unroll
         for (int k = 0; k < C::NLD; ++k) {
             const int e = tid + k * 256;
@@ -397,10 +508,17 @@ __global__ __launch_bounds__(256, C::SPLIT ? WG_WPE : 1) void conv3x3_wgrad_bf16
                 *(uint4*)(s_in + (e / C::C8) * C::S + (e % C::C8) * 8) = v;
             }
         }
+        if constexpr (POOLED) {
+            unsigned short* s_pd = s_do + C::DO_ELEMS;
+            ps.store(s_pd);
+            __syncthreads();
+            PS::gather(s_pd, ty_cur / 2, ty_cur, ty_cur + C::TH, s_do, ty_cur, C::TW, 0, C::SO);
+        } else {
 #pragma unroll
-        for (int k = 0; k < C::NDO; ++k) {
-            const int e = tid + k * 256;
-            if (e < C::NT * C::OC8) *(uint4*)(s_do + (e / C::OC8) * C::SO + (e % C::OC8) * 8) = rdo[k];
+            for (int k = 0; k < C::NDO; ++k) {
+                const int e = tid + k * 256;
+                if (e < C::NT * C::OC8) *(uint4*)(s_do + (e / C::OC8) * C::SO + (e % C::OC8) * 8) = rdo[k];
+            }
         }
         TCK(2);
         __syncthreads();
@@ -545,13 +663,15 @@ static int wb_grid(int n) {
     const int w = (C::NIMG > 1) ? (n + C::NIMG - 1) / C::NIMG : n * C::TPI;
     return w > 256 * bpc ? 256 * bpc : w;
 }
-template <class C>
+template <class C, bool POOLED = false>
 static void launch_wb_t(const WgradArgs& a, hipStream_t st) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    constexpr size_t TILE = C::TILE_BYTES + (POOLED ? PoolStage<C::COUT, C::HW / 2, C::TH / 2 + 1>::BYTES : 0);
+    constexpr size_t LDS = TILE > C::RED_BYTES ? TILE : C::RED_BYTES;
+    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<C, POOLED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
     const int grid = wb_grid<C>(a.n);
     if (grid < 1) return;
-    hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<C, POOLED>), dim3(grid), dim3(256), LDS, st, a);
 }
 int wgrad_grid_bf16(ConvShape s, int n) {
     switch (s) {
@@ -566,8 +686,8 @@ int wgrad_grid_bf16(ConvShape s, int n) {
 void launch_conv_wgrad_bf16(ConvShape s, const WgradArgs& a, hipStream_t st) {
     switch (s) {
         case CS_16_16_32: launch_wb_t<WT_16_16_32>(a, st); break;
-        case CS_16_32_32: launch_wb_t<WT_16_32_32>(a, st); break;
-        case CS_32_32_16: launch_wb_t<WT_32_32_16>(a, st); break;
+        case CS_16_32_32: if (a.pool_arg) launch_wb_t<WT_16_32_32, true>(a, st); else launch_wb_t<WT_16_32_32>(a, st); break;
+        case CS_32_32_16: if (a.pool_arg) launch_wb_t<WT_32_32_16, true>(a, st); else launch_wb_t<WT_32_32_16>(a, st); break;
         case CS_32_32_8:  launch_wb_t<WT_32_32_8>(a, st); break;
         default: break;
     }
@@ -959,16 +1079,17 @@ using BD_16_32_32 = BfCfg<32, 16, 32,  8, 32, 1, true>;
 using BD_32_32_16 = BfCfg<32, 32, 16, 16, 16, 1, true>;
 using BD_32_32_8  = BfCfg<32, 32,  8,  8,  8, 4, true>;
 
-template <class C>
+template <class C, bool POOLIN = false>
 static void launch_bf_t(const ConvArgs& a, hipStream_t st) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
-    int bpc = (int)((160 * 1024) / C::LDS_BYTES);
+    constexpr size_t LDS = C::LDS_BYTES + (POOLIN ? PoolStage<C::CIN, C::HW / 2, C::TH / 2 + 3>::BYTES : 0);
+    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<C, POOLIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    int bpc = (int)((160 * 1024) / LDS);
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
     int grid = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
     if (grid > 256 * bpc) grid = 256 * bpc;
     if (grid < 1) return;
-    hipLaunchKernelGGL(conv3x3_bf16_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<C, POOLIN>), dim3(grid), dim3(256), LDS, st, a);
 }
 
 void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
@@ -983,8 +1104,8 @@ void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
 void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
     switch (s) {
         case CS_16_16_32: launch_bf_t<BD_16_16_32>(a, st); break;
-        case CS_16_32_32: launch_bf_t<BD_16_32_32>(a, st); break;
-        case CS_32_32_16: launch_bf_t<BD_32_32_16>(a, st); break;
+        case CS_16_32_32: if (a.pool_arg) launch_bf_t<BD_16_32_32, true>(a, st); else launch_bf_t<BD_16_32_32>(a, st); break;
+        case CS_32_32_16: if (a.pool_arg) launch_bf_t<BD_32_32_16, true>(a, st); else launch_bf_t<BD_32_32_16>(a, st); break;
         case CS_32_32_8:  launch_bf_t<BD_32_32_8>(a, st); break;
         default: break;
     }

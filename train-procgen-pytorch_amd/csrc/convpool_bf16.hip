@@ -1,0 +1,189 @@
+// First conv of an IMPALA block fused with the block's MaxPool2d(3, 2, 1) for the bf16 mode (block2.conv 16 -> 32 @32x32,
+// block3.conv 32 -> 32 @16x16; block1.conv has its own uint8-input kernel in conv_bf16.hip) -- common/model.py:150-163.
+//
+// forward : a work item produces 4 pooled rows of one image from 9 conv rows (one halo row recomputed), which live in
+//           LDS only: the conv output, the largest tensor of the block, is neither written to nor re-read from HBM; the
+//           backward pass needs the pooled arg-max, not the conv output.
+// backward: the gradient of the conv output is never materialised either.  pool_bwd_stage() rebuilds any window of it
+//           in LDS from (pooled gradient, arg-max bytes) for the conv's weight-gradient and data-gradient kernels.
+#include "common.h"
+#include <math.h>
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ unsigned short cp_f2bf(float x) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
+
+template <int CIN_, int COUT_, int HW_>
+struct CpCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, HW = HW_, HO = HW / 2;
+    static constexpr int S = (CIN == 16) ? 16 : 48;                  // staged-pixel stride (conflict-free, see conv_bf16.hip)
+    static constexpr int CR = 9, PH = CR + 2, PW = HW + 2;           // conv rows per item, staged input rows / cols
+    static constexpr int IN_ELEMS = ((PH * PW * S + 7) / 8) * 8;
+    static constexpr int NK = (CIN == 32) ? 9 : 5, WS = NK * 32 + 16, W_ELEMS = COUT * WS;
+    static constexpr int SC_ELEMS = CR * HW * COUT;                  // conv-output tile [row][col][channel]
+    static constexpr int NMT = CR * HW / 16, MT = (NMT + 3) / 4, NB = COUT / 16, C8 = CIN / 8;
+    static constexpr int NSRC = PH * HW * C8, NLD = (NSRC + 255) / 256;
+    static constexpr int IPI = HO / 4;                               // items per image (4 pooled rows each)
+    static constexpr int NPOOL = 4 * HO * (COUT / 8);                // pooling tasks per item: (row, col, 8-channel group)
+    static constexpr size_t LDS_BYTES = (size_t)(IN_ELEMS + W_ELEMS + SC_ELEMS) * 2;
+    static_assert((CR * HW) % 16 == 0 && HO % 4 == 0 && NPOOL <= 256, "tiling");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void conv_pool_fwd_bf16_kernel(ConvArgs a, unsigned short* p_out, uint8_t* p_arg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_in = smem_h;
+    unsigned short* s_w = smem_h + C::IN_ELEMS;
+    unsigned short* s_c = s_w + C::W_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const unsigned short* g_in = (const unsigned short*)a.in;
+    for (int e = tid; e < C::W_ELEMS / 8; e += 256) ((uint4*)s_w)[e] = ((const uint4*)a.wbank)[e];
+    for (int e = tid; e < C::IN_ELEMS / 8; e += 256) ((uint4*)s_in)[e] = (uint4){0u, 0u, 0u, 0u};          // column halos stay zero
+    float bias_r[C::NB][4];
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_r[nb][r] = a.bias ? a.bias[nb * 16 + kq * 4 + r] : 0.f;
+    int koff[C::NK];
+#pragma unroll
+    for (int m = 0; m < C::NK; ++m) {
+        int tap, chunk;
+        if (C::CIN == 32) { tap = m; chunk = kq; } else { tap = 2 * m + (kq >> 1); chunk = kq & 1; if (tap > 8) tap = 8; }
+        koff[m] = ((tap / 3) * C::PW + (tap % 3)) * C::S + chunk * 8;
+    }
+    const int nwork = a.n * C::IPI;
+    uint4 regs[C::NLD];
+    // staged row r = image row (first conv row of the item) - 1 + r; the item's first conv row is 2*oy0 - 1
+    auto load = [&](int work) {
+        const int img = work / C::IPI, gy0 = 2 * (work % C::IPI) * 4 - 2;
+#pragma unroll
+        for (int k = 0; k < C::NLD; ++k) {
+            const int e = tid + k * 256;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (e < C::NSRC) {
+                const int c8 = e % C::C8, px = (e / C::C8) % C::HW, r = e / (C::C8 * C::HW), gy = gy0 + r;
+                if (gy >= 0 && gy < C::HW) v = *(const uint4*)(g_in + (((long long)img * C::HW + gy) * C::HW + px) * C::CIN + c8 * 8);
+            }
+            regs[k] = v;
+        }
+    };
+    if ((int)blockIdx.x < nwork) load(blockIdx.x);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int img = work / C::IPI, oy0 = (work % C::IPI) * 4, cy0 = 2 * oy0 - 1;      // first conv row of the item (may be -1)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < C::NLD; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::NSRC) {
+                const int c8 = e % C::C8, px = (e / C::C8) % C::HW, r = e / (C::C8 * C::HW);
+                *(uint4*)(s_in + (r * C::PW + px + 1) * C::S + c8 * 8) = regs[k];
+            }
+        }
+        __syncthreads();
+        if (work + (int)gridDim.x < nwork) load(work + gridDim.x);
+
+        // ---- conv: tile t = wave + 4k covers 16 consecutive pixels of the 9 x HW conv rows -> s_c (bf16, + bias)
+        {
+            f32x4 acc[C::MT][C::NB];
+            int abase[C::MT], cbase[C::MT];
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+                int t = wave + 4 * mt;
+                const bool live = t < C::NMT;
+                t = live ? t : C::NMT - 1;
+                const int pl = t * 16 + i, y = pl / C::HW, x = pl % C::HW;
+                abase[mt] = (y * C::PW + x) * C::S;
+                cbase[mt] = live ? pl * C::COUT + kq * 4 : -1;
+#pragma unroll
+                for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const int bbase = i * C::WS + kq * 8;
+#pragma unroll
+            for (int m = 0; m < C::NK; ++m) {
+                bf16x8 av[C::MT], bv[C::NB];
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt) av[mt] = *(const bf16x8*)(s_in + abase[mt] + koff[m]);
+#pragma unroll
+                for (int nb = 0; nb < C::NB; ++nb) bv[nb] = *(const bf16x8*)(s_w + bbase + nb * 16 * C::WS + m * 32);
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+                if (cbase[mt] < 0) continue;
+#pragma unroll
+                for (int nb = 0; nb < C::NB; ++nb)
+                    *(uint2*)(s_c + cbase[mt] + nb * 16) =
+                        (uint2){(unsigned)cp_f2bf(acc[mt][nb][0] + bias_r[nb][0]) | ((unsigned)cp_f2bf(acc[mt][nb][1] + bias_r[nb][1]) << 16),
+                                (unsigned)cp_f2bf(acc[mt][nb][2] + bias_r[nb][2]) | ((unsigned)cp_f2bf(acc[mt][nb][3] + bias_r[nb][3]) << 16)};
+            }
+        }
+        __syncthreads();
+        // ---- pooling: thread = (pooled row 0..3, pooled col, 8-channel group).  The 9 window reads are issued up front
+        // (clamped addresses); a position outside the image (top row of the image, left column) is masked and the first
+        // VALID position is always taken -- the tie / NaN rule of the stand-alone max-pool kernel (misc.hip).
+        if (tid < C::NPOOL) {
+            constexpr int G8 = C::COUT / 8;
+            const int c8 = tid % G8, ox = (tid / G8) % C::HO, oyl = tid / (G8 * C::HO);
+            const int ky0 = (cy0 + 2 * oyl < 0) ? 1 : 0, kx0 = (ox == 0) ? 1 : 0;
+            uint4 u[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int x = 2 * ox - 1 + kx;
+                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * C::HW + (x < 0 ? 0 : x)) * C::COUT + c8 * 8);
+                }
+            float best[8];
+            unsigned bi[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bool valid = (ky >= ky0) && (kx >= kx0), isfirst = (ky == ky0) && (kx == kx0);
+                    const unsigned w[4] = {u[ky * 3 + kx].x, u[ky * 3 + kx].y, u[ky * 3 + kx].z, u[ky * 3 + kx].w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float v = (q & 1) ? __uint_as_float(w[q >> 1] & 0xffff0000u) : __uint_as_float(w[q >> 1] << 16);
+                        if (valid && (isfirst || v > best[q] || v != v)) { best[q] = v; bi[q] = ky * 3 + kx; }
+                    }
+                }
+            const size_t o = ((((size_t)img * C::HO + oy0 + oyl) * C::HO + ox) * G8 + c8) * 8;
+            uint4 pk;                                        // best[] are bf16 values widened to fp32: the high halves are the bits
+            pk.x = (__float_as_uint(best[0]) >> 16) | (__float_as_uint(best[1]) & 0xffff0000u);
+            pk.y = (__float_as_uint(best[2]) >> 16) | (__float_as_uint(best[3]) & 0xffff0000u);
+            pk.z = (__float_as_uint(best[4]) >> 16) | (__float_as_uint(best[5]) & 0xffff0000u);
+            pk.w = (__float_as_uint(best[6]) >> 16) | (__float_as_uint(best[7]) & 0xffff0000u);
+            *(uint4*)(p_out + o) = pk;
+            *(uint2*)(p_arg + o) = (uint2){bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24)};
+        }
+    }
+}
+
+using CP_16_32_32 = CpCfg<16, 32, 32>;
+using CP_32_32_16 = CpCfg<32, 32, 16>;
+
+template <class C>
+static void launch_cp_t(const ConvArgs& a, void* p_out, uint8_t* p_arg, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)conv_pool_fwd_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    int bpc = (int)((160 * 1024) / C::LDS_BYTES);
+    bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
+    int grid = a.n * C::IPI;
+    if (grid > 256 * bpc) grid = 256 * bpc;
+    if (grid < 1) return;
+    hipLaunchKernelGGL(conv_pool_fwd_bf16_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, st, a, (unsigned short*)p_out, p_arg);
+}
+// a.in (bf16 NHWC), a.wbank (packed forward bank), a.bias, a.n; returns false when the shape has no fused kernel
+bool launch_conv_pool_fwd_bf16(ConvShape s, const ConvArgs& a, void* p_out, uint8_t* p_arg, hipStream_t st) {
+    if (!a.wbank) return false;
+    switch (s) {
+        case CS_16_32_32: launch_cp_t<CP_16_32_32>(a, p_out, p_arg, st); return true;
+        case CS_32_32_16: launch_cp_t<CP_32_32_16>(a, p_out, p_arg, st); return true;
+        default: return false;
+    }
+}

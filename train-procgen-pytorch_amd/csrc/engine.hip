@@ -274,7 +274,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         for (int k = 0; k < 3; ++k) HIPC(dalloc(&c->GP[k], (size_t)NB * 32 * 32 * 16));
         c->slab_floats = (size_t)1024 * (32 * 9 * 32 + 32);      // persistent grids never exceed 4 workgroups x 256 CUs
         HIPC(dalloc(&c->slabs, c->slab_floats));
-        HIPC(dalloc(&c->fs_scratch, (size_t)64 * 2048));
+        HIPC(dalloc(&c->fs_scratch, (size_t)128 * 2048));      // FS_GROUPS x 2048 partial column maxima (misc.hip)
     } else {
         c->obs_bytes_per_env = (size_t)cfg->obs_dim * sizeof(float);
         HIPC(dalloc(&c->obsf, (size_t)(T + 1) * E * cfg->obs_dim));
@@ -555,8 +555,9 @@ static void conv_fwd(mi_ctx* c, const ConvLayer& L, const void* in, const InputS
     ProfScope ps(c, PC_CONV_FWD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : es * L.cin) + es * L.cout * (res ? 2 : 1)), px * 18.0 * L.cin * L.cout);
     launch_conv_fwd(L.shape, a, c->stream);
 }
-static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const float* mask, const float* res, float* din, int n) {
+static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const float* mask, const float* res, float* din, int n, const uint8_t* pool_arg = nullptr) {
     ConvArgs a{};
+    a.pool_arg = pool_arg;
     a.in = dout; a.w = c->params + L.w_off; a.bias = nullptr; a.res = res; a.mask = mask; a.out = din;
     a.lut = c->lut; a.n = n; a.relu_in = 0; a.bf16 = c->bf;
     a.wbank = (c->bf && L.bank_d >= 0) ? c->banks + L.bank_d : nullptr;
@@ -644,6 +645,12 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
                 const double px = (double)n * 64 * 64;
                 ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, px * 3.0 + px / 4 * 16 * 3.0, px * 18.0 * 3 * 16);
                 launch_conv1_pool_fwd_bf16(a, c->lut16, k.P0, k.PI, c->stream);
+            } else if (c->bf && L[0].bank_f >= 0) {       // block2.conv / block3.conv + max pool fused as well (convpool_bf16.hip)
+                ConvArgs a{};
+                a.in = prev; a.bias = c->params + L[0].b_off; a.n = n; a.bf16 = 1; a.wbank = c->banks + L[0].bank_f;
+                const double px = (double)n * L[0].hw * L[0].hw;
+                ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, px * 2.0 * L[0].cin + px / 4 * L[0].cout * 3.0, px * 18.0 * L[0].cin * L[0].cout);
+                if (!launch_conv_pool_fwd_bf16(L[0].shape, a, k.P0, k.PI, c->stream)) { fprintf(stderr, "mi355ppo: no fused conv+pool kernel for this shape\n"); abort(); }
             } else {
             if (b == 0) conv_fwd(c, L[0], nullptr, &src, 0, nullptr, k.C, n);
             else conv_fwd(c, L[0], prev, nullptr, 0, nullptr, k.C, n);
@@ -753,6 +760,12 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         }
         // max pool, then the block's first conv
         if (b == 0 && c->bf) { conv_wgrad(c, L[0], nullptr, &src, 0, Gout, n, k.PI); break; }     // pool backward fused into the staging
+        if (c->bf) {            // blocks 2, 3: both consumers of the conv-output gradient rebuild it from (pooled gradient, arg-max)
+            conv_wgrad(c, L[0], c->blk[b - 1].P2, nullptr, 0, Gout, n, k.PI);
+            conv_dgrad(c, L[0], Gout, nullptr, nullptr, Ga, n, k.PI);
+            std::swap(Gout, Ga);
+            continue;
+        }
         { ProfScope ps(c, PC_POOL_BWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
           if (c->bf) launch_maxpool_bwd_bf16(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); else launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); }
         if (b == 0) conv_wgrad(c, L[0], nullptr, &src, 0, c->GC, n);
@@ -1095,18 +1108,28 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
         if (in_is_u8) { HIPC(hipMalloc(&din, px * 3 + 256)); HIPC(hipMemcpy(din, in, px * 3, hipMemcpyHostToDevice)); }
         else if (int r = upload_act(c, (const float*)in, px * cin, &din)) return r;
     }
-    if (mode >= 3) {        // block1.conv fused with its max pool (bf16): 3 = forward -> pooled map, 4 = weight gradient from the pooled gradient
-        ARG(s == CS_3_16_64 && c->bf, "fused conv+pool modes exist for block1.conv in bf16 precision only");
-        const size_t pp = (size_t)n * 32 * 32 * 16;
-        void* dp = nullptr; uint8_t* di = nullptr;
+    if (mode >= 3) {        // a block's first conv fused with the block's max pool (bf16): 3 = forward -> pooled map,
+                            // 4 = weight gradient, 5 = data gradient -- both from the POOLED gradient + the forward's arg-max bytes
+        ARG(c->bf && (s == CS_3_16_64 || s == CS_16_32_32 || s == CS_32_32_16), "fused conv+pool modes: block1/2/3.conv in bf16 precision only");
+        ARG(mode <= 5 && !(mode == 5 && s == CS_3_16_64) && in, "mode");
+        const size_t pp = (size_t)n * (hw / 2) * (hw / 2) * cout;
+        void *dp = nullptr, *dgi = nullptr; uint8_t* di = nullptr; unsigned short* dbank = nullptr; BankDesc* ddesc = nullptr;
         HIPC(hipMalloc(&dp, pp * 2 + 256)); HIPC(dalloc(&di, pp));
         ConvArgs a{};
         a.in = din; a.w = dw; a.bias = db; a.n = n; a.bf16 = 1; a.lut16 = c->lut16;
-        launch_conv1_pool_fwd_bf16(a, c->lut16, dp, di, c->stream);
+        if (s == CS_3_16_64) launch_conv1_pool_fwd_bf16(a, c->lut16, dp, di, c->stream);
+        else {
+            const long long bf_len = (long long)cout * bank_ws(cin), bd_len = (long long)cin * bank_ws(cout);
+            BankDesc d[2] = {{0, 0, cout, cin, cout, cin, 0, bank_ws(cin), cin == 32 ? 9 : 5}, {0, bf_len, cin, cout, cout, cin, 1, bank_ws(cout), cout == 32 ? 9 : 5}};
+            HIPC(dalloc(&dbank, (size_t)(bf_len + bd_len))); HIPC(hipMalloc((void**)&ddesc, sizeof d)); HIPC(hipMemcpy(ddesc, d, sizeof d, hipMemcpyHostToDevice));
+            launch_pack_banks(dw, dbank, ddesc, 2, c->stream);
+            a.wbank = dbank;
+            ARG(launch_conv_pool_fwd_bf16(s, a, dp, di, c->stream), "no fused kernel");
+        }
         HIPC(hipGetLastError());
         HIPC(hipStreamSynchronize(c->stream));
         if (mode == 3) { if (int r = download_act(c, dp, out, pp)) return r; }
-        else {
+        else if (mode == 4) {
             ARG(dout && c->slabs, "dout");
             if (int r = upload_act(c, dout, pp, &ddout)) return r;
             float* g = nullptr;
@@ -1123,8 +1146,18 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
             to_ref_layout(td, hg.data(), out);
             if (dbias_out) memcpy(dbias_out, hg.data() + td.n, cout * 4);
             hipFree(g);
+        } else {
+            ARG(dout, "dout");
+            if (int r = upload_act(c, dout, pp, &ddout)) return r;
+            HIPC(hipMalloc(&dgi, px * cin * 2 + 256));
+            ConvArgs g{};
+            g.in = ddout; g.pool_arg = di; g.w = dw; g.out = dgi; g.n = n; g.bf16 = 1; g.wbank = dbank + (long long)cout * bank_ws(cin);
+            launch_conv_dgrad(s, g, c->stream);
+            HIPC(hipGetLastError());
+            HIPC(hipStreamSynchronize(c->stream));
+            if (int r = download_act(c, dgi, out, px * cin)) return r;
         }
-        void* fr[] = {dw, db, din, ddout, dp, di};
+        void* fr[] = {dw, db, din, ddout, dp, di, dbank, ddesc, dgi};
         for (void* p : fr) if (p) hipFree(p);
         return 0;
     }

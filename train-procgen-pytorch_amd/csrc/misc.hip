@@ -546,33 +546,48 @@ void launch_loss_bwd(const LossArgs& a, hipStream_t st) {
 
 // feature-sparsity metric (common/model.py:207): mean_j max_b tanh(|100*relu(h_bj)|)
 // = mean_j tanh(100 * max_b relu(h_bj)) (tanh monotone).  flat_pre is block3's output BEFORE the ReLU.
-__global__ void colmax_partial_kernel(const void* x, int bf16, int n, int d, float* part) {
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63), rg = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int groups = gridDim.y * 4;
-    float m = 0.f;
-    if (j < d) {
-        for (int b = rg; b < n; b += groups) {
+// FS_GROUPS row groups x d columns of partial maxima; a thread owns 8 consecutive columns (16-byte bf16 / 2 x 16-byte
+// fp32 loads), a workgroup walks whole rows.
+constexpr int FS_GROUPS = 128;
+__global__ __launch_bounds__(256) void colmax_partial_kernel(const void* x, int bf16, int n, int d, float* part) {
+    for (int j = threadIdx.x * 8; j < d; j += 256 * 8) {
+        float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = blockIdx.x; b < n; b += FS_GROUPS) {
             const long long o = (long long)b * d + j;
-            m = fmaxf(m, bf16 ? __uint_as_float(((unsigned)((const unsigned short*)x)[o]) << 16) : ((const float*)x)[o]);
+            if (bf16) {
+                const uint4 u = *(const uint4*)((const unsigned short*)x + o);
+                const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], (k & 1) ? __uint_as_float(w[k >> 1] & 0xffff0000u) : __uint_as_float(w[k >> 1] << 16));
+            } else {
+                const f32x4 lo = *(const f32x4*)((const float*)x + o), hi = *(const f32x4*)((const float*)x + o + 4);
+                m[0] = fmaxf(m[0], lo.x); m[1] = fmaxf(m[1], lo.y); m[2] = fmaxf(m[2], lo.z); m[3] = fmaxf(m[3], lo.w);
+                m[4] = fmaxf(m[4], hi.x); m[5] = fmaxf(m[5], hi.y); m[6] = fmaxf(m[6], hi.z); m[7] = fmaxf(m[7], hi.w);
+            }
         }
-        part[(long long)rg * d + j] = m;
+        float* p = part + (long long)blockIdx.x * d + j;
+        *(f32x4*)p = (f32x4){m[0], m[1], m[2], m[3]};
+        *(f32x4*)(p + 4) = (f32x4){m[4], m[5], m[6], m[7]};
     }
 }
-__global__ __launch_bounds__(256) void fs_finalize_kernel(const float* part, int groups, int d, float* fs_out) {
-    __shared__ double sb[4];
+__global__ __launch_bounds__(1024) void fs_finalize_kernel(const float* part, int groups, int d, float* fs_out) {
+    __shared__ double sb[16];
     double s = 0.0;
-    for (int j = threadIdx.x; j < d; j += 256) {
+    for (int j = threadIdx.x; j < d; j += 1024) {
         float m = 0.f;
         for (int g = 0; g < groups; ++g) m = fmaxf(m, part[(long long)g * d + j]);
         s += (double)tanhf(fabsf(m * 100.f));
     }
-    const double tot = block_sum256(s, sb);
-    if (threadIdx.x == 0) fs_out[0] = (float)(tot / d);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sb[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double tot = 0.0; for (int k = 0; k < 16; ++k) tot += sb[k]; fs_out[0] = (float)(tot / d); }
 }
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(colmax_partial_kernel, dim3((d + 63) / 64, 16), dim3(256), 0, st, flat_pre, bf16, n, d, colmax_scratch);
-    hipLaunchKernelGGL(fs_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)colmax_scratch, 64, d, fs_out);
+    if (d % 8) abort();                                       // the flattened IMPALA feature map (2048)
+    hipLaunchKernelGGL(colmax_partial_kernel, dim3(FS_GROUPS), dim3(256), 0, st, flat_pre, bf16, n, d, colmax_scratch);
+    hipLaunchKernelGGL(fs_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)colmax_scratch, FS_GROUPS, d, fs_out);
 }
 
 // ------------------------------------------------------------------------------------------ GAE scan

@@ -314,7 +314,8 @@ class Engine:
     def op_conv3x3(self, mode, cin, cout, hw, w_ref, inp=None, relu_in=False, bias=None, res=None, mask=None, dout=None):
         is_u8 = inp is not None and inp.dtype == np.uint8
         n = (inp if inp is not None else dout).shape[0]
-        # modes: 0 forward, 1 dgrad, 2 wgrad; block1.conv in bf16 precision also 3 = conv+maxpool forward, 4 = wgrad from the pooled gradient
+        # modes: 0 forward, 1 dgrad, 2 wgrad; a block's first conv in bf16 precision also 3 = conv+maxpool forward,
+        # 4 / 5 = weight / data gradient from the POOLED gradient (dout) and the forward's arg-max (inp is needed for it)
         inp = None if inp is None else np.ascontiguousarray(inp)
         w_ref = _f32(w_ref)
         bias, res, mask, dout = (None if a is None else _f32(a) for a in (bias, res, mask, dout))
@@ -322,6 +323,8 @@ class Engine:
             out, db = np.empty((cout, cin, 3, 3), np.float32), np.empty(cout, np.float32)
         elif mode == 3:
             out, db = np.empty((n, hw // 2, hw // 2, cout), np.float32), None
+        elif mode == 5:
+            out, db = np.empty((n, hw, hw, cin), np.float32), None
         else:
             out, db = np.empty((n, hw, hw, cin if mode == 1 else cout), np.float32), None
         self._chk(self.lib.mi_op_conv3x3(self._ctx, C.c_int32(mode), C.c_int32(cin), C.c_int32(cout), C.c_int32(hw),
