@@ -35,21 +35,25 @@ struct FcNtArgs {
     int a_f32, relu_a, relu_out, c_bf16;
 };
 constexpr int NT_LD = 80;                                // LDS row stride (bf16 elements): 10 x 16-B slots, conflict free
-template <bool A_F32>
+// TM = rows of C per workgroup (128, or 64 when the grid would otherwise leave CUs with a single workgroup); a wave owns
+// TM/4 rows x 64 columns.  The MFMA takes the B-tile rows (n) as its A operand and the A-tile rows (m) as B, so a lane's 4
+// accumulator registers are 4 CONSECUTIVE n of one row m: bias / mask / output move as 16- or 8-byte words.
+template <bool A_F32, int TM>
 __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[128 * NT_LD];
+    constexpr int MA = TM / 64;                          // 16-row tiles per wave
+    __shared__ __attribute__((aligned(16))) unsigned short As[TM * NT_LD];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[64 * NT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 64;
-    f32x4 acc[2][4];
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 64;
+    f32x4 acc[MA][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MA; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint4 ra[4], rb[2];
+    uint4 ra[TM / 32], rb[2];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {                    // A tile: 128 rows x 8 chunks of 8 elements
+        for (int e = 0; e < TM / 32; ++e) {              // A tile: TM rows x 8 chunks of 8 elements
             const int l = tid + e * 256, r = l >> 3, c8 = l & 7;
             uint4 v = {0u, 0u, 0u, 0u};
             if (m0 + r < g.M) {
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs g) {
     for (int k0 = 0; k0 < g.K; k0 += 64) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < TM / 32; ++e) {
             const int l = tid + e * 256;
             uint4 v = ra[e];
             if (g.relu_a) { v.x = fc_relu2(v.x); v.y = fc_relu2(v.y); v.z = fc_relu2(v.z); v.w = fc_relu2(v.w); }
@@ -87,39 +91,56 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs g) {
         if (k0 + 64 < g.K) fetch(k0 + 64);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 av[2], bv[4];
+            bf16x8 av[MA], bv[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) av[a] = *(const bf16x8*)(As + (wave * 32 + a * 16 + i) * NT_LD + ks * 32 + kq * 8);
+            for (int a = 0; a < MA; ++a) av[a] = *(const bf16x8*)(As + (wave * (TM / 4) + a * 16 + i) * NT_LD + ks * 32 + kq * 8);
 #pragma unroll
             for (int b = 0; b < 4; ++b) bv[b] = *(const bf16x8*)(Bs + (b * 16 + i) * NT_LD + ks * 32 + kq * 8);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < MA; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = MFMA_BF16(av[a], bv[b], acc[a][b]);
+                for (int b = 0; b < 4; ++b) acc[a][b] = MFMA_BF16(bv[b], av[a], acc[a][b]);
         }
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MA; ++a) {
+        const int m = m0 + wave * (TM / 4) + a * 16 + i;
+        if (m >= g.M) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 4; ++b) {
+            const int n = n0 + b * 16 + kq * 4;          // n .. n+3 (N is a multiple of 64 for both uses)
+            if (n >= g.N) continue;
+            const long long o = (long long)m * g.N + n;
+            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            if (g.bias) { const f32x4 bb = *(const f32x4*)(g.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+            if (g.relu_out) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wave * 32 + a * 16 + kq * 4 + r, n = n0 + b * 16 + i;
-                if (m < g.M && n < g.N) {
-                    const long long o = (long long)m * g.N + n;
-                    float v = acc[a][b][r];
-                    if (g.bias) v += g.bias[n];
-                    if (g.relu_out) v = fmaxf(v, 0.f);
-                    if (g.mask) v = (g.mask[o] & 0x8000u) || g.mask[o] == 0 ? 0.f : v;      // mask > 0  (bf16 bits)
-                    if (g.c_bf16) ((unsigned short*)g.C)[o] = fc_f2bf(v); else ((float*)g.C)[o] = v;
-                }
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
+            if (g.mask) {                                 // mask > 0 (bf16 bits: not negative, not zero)
+                const uint2 mk = *(const uint2*)(g.mask + o);
+                const unsigned h[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = ((h[r] & 0x8000u) || h[r] == 0) ? 0.f : v[r];
+            }
+            if (g.c_bf16) *(uint2*)((unsigned short*)g.C + o) = (uint2){fc_pack2(v[0], v[1]), fc_pack2(v[2], v[3])};
+            else *(f32x4*)((float*)g.C + o) = (f32x4){v[0], v[1], v[2], v[3]};
+        }
+    }
 }
 void launch_fc_nt(const FcNtArgs& g, hipStream_t st) {
     if (g.M <= 0) return;
-    dim3 grid((g.N + 63) / 64, (g.M + 127) / 128);
-    if (g.a_f32) hipLaunchKernelGGL(fc_nt_kernel<true>, grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(fc_nt_kernel<false>, grid, dim3(256), 0, st, g);
+    const int tn = (g.N + 63) / 64;
+    const bool small_grid = (long long)tn * ((g.M + 127) / 128) < 512;         // fewer than 2 workgroups per CU with 128-row tiles
+    if (small_grid) {
+        dim3 grid(tn, (g.M + 63) / 64);
+        if (g.a_f32) hipLaunchKernelGGL((fc_nt_kernel<true, 64>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((fc_nt_kernel<false, 64>), grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid(tn, (g.M + 127) / 128);
+        if (g.a_f32) hipLaunchKernelGGL((fc_nt_kernel<true, 128>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((fc_nt_kernel<false, 128>), grid, dim3(256), 0, st, g);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ TN (weight gradient)

@@ -375,15 +375,26 @@ __global__ void colsum_partial_kernel(const float* dY, int M, int N, int ld, flo
     const int n = blockIdx.x * 64 + (threadIdx.x & 63), rg = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int groups = gridDim.y * 4;
     float s = 0.f;
-    if (n < N) for (int m = rg; m < M; m += groups) s += dY[(long long)m * ld + n];
-    if (n < N) part[(long long)rg * N + n] = s;
+    if (n < N) {
+        int m = rg;
+        for (; m + 7 * groups < M; m += 8 * groups) {        // 8 loads in flight; the adds keep row order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = dY[(long long)(m + q * groups) * ld + n];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; m < M; m += groups) s += dY[(long long)m * ld + n];
+        part[(long long)rg * N + n] = s;
+    }
 }
 static float* g_col_ws = nullptr;
 void colsum_set_workspace(float* ws) { g_col_ws = ws; }
 void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, hipStream_t st) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, 16), dim3(256), 0, st, dY, M, N, ld, g_col_ws);
-    launch_reduce_slabs(g_col_ws, 64, N, db, N, nullptr, 0, st);
+    const int gy = (M >= 4096 && N <= 1024) ? 64 : 16;         // workspace: 64 x 4096 floats (engine.hip)
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, st, dY, M, N, ld, g_col_ws);
+    launch_reduce_slabs(g_col_ws, gy * 4, N, db, N, nullptr, 0, st);
 }
 
 __global__ void gather_rows_kernel(const float* src, const int32_t* idx, long long base, float* dst, int n, int d) {
@@ -575,6 +586,7 @@ __global__ __launch_bounds__(1024) void fs_finalize_kernel(const float* part, in
     double s = 0.0;
     for (int j = threadIdx.x; j < d; j += 1024) {
         float m = 0.f;
+#pragma unroll 16
         for (int g = 0; g < groups; ++g) m = fmaxf(m, part[(long long)g * d + j]);
         s += (double)tanhf(fabsf(m * 100.f));
     }

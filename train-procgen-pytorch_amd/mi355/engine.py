@@ -61,6 +61,9 @@ def load_library():
     lib.mi_host_free.argtypes = [C.c_void_p]
     lib.mi_host_free.restype = None
     lib.mi_profile_class_name.restype = C.c_char_p
+    # the per-env-step entry point is called T+1 times per iteration: declared argtypes let plain ints / addresses through
+    # without building ctypes wrapper objects on every call
+    lib.mi_rollout_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -202,8 +205,11 @@ class Engine:
         rew_prev = None if rew_prev is None else _f32(rew_prev)
         done_prev = None if done_prev is None else _f32(done_prev)
         act, logp, val = np.empty(self.E, np.int64), np.empty(self.E, np.float32), np.empty(self.E, np.float32)
-        self._chk(self.lib.mi_rollout_step(self._ctx, C.c_int32(t), _fp(rew_prev), _fp(done_prev), C.c_uint64(seed), _fp(u),
-                                           _fp(act), _fp(logp), _fp(val)))
+        rc = self.lib.mi_rollout_step(self._ctx, t, None if rew_prev is None else rew_prev.ctypes.data,
+                                      None if done_prev is None else done_prev.ctypes.data, seed, None if u is None else u.ctypes.data,
+                                      act.ctypes.data, logp.ctypes.data, val.ctypes.data)
+        if rc:
+            self._chk(rc)
         return act, logp, val
 
     def predict_staged(self, obs, seed=0, counter=0, u=None):
