@@ -68,17 +68,26 @@ def cpu_baseline(T, n_samples, threads):
 
 
 def rocprof_name(cls, precision):
-    """kernel class of the live profiler -> substring of the rocprofv3 kernel name (template arguments)."""
-    kind, cin, cout, hw = cls.split("_")[1], *[int(x) for x in cls.split("_")[2:5]]
-    if cin == 3:
-        return ("conv3x3_wgrad_kernel<WgCfg<3, 4, 16, 64" if kind == "wgrad" else "conv3x3_kernel<FwdCfg<3, 4, 16, 64")
+    """kernel class of the live profiler -> substrings that identify its rocprofv3 kernel name (template arguments)."""
+    parts = cls.split("_")
+    kind, cin, cout, hw = parts[1], *[int(x) for x in parts[2:5]]
+    if parts[0] == "resblock":                        # fused residual block (bf16 mode): RbCfg<C, HW, TH, NIMG>, BWD
+        return [f"resblock_bf16_kernel<RbCfg<{cin}, {hw},", ", true>" if kind == "dgrad" else ", false>"]
     if precision == "bf16":
-        if kind == "wgrad":
-            return f"conv3x3_wgrad_bf16_kernel<WbCfg<{cin}, {cout}, {hw},"
-        return f"conv3x3_bf16_kernel<BfCfg<{cin}, {cout}, {hw}," if kind == "fwd" else f"conv3x3_bf16_kernel<BfCfg<{cout}, {cin}, {hw},"
+        if cin == 3:
+            return ["conv1_wgrad_bf16_kernel<true>"] if kind == "wgrad" else ["conv1_pool_fwd_bf16_kernel"]
+        if kind == "wgrad":                           # POOLED variant for a block's first conv (cin != cout or block3.conv; the
+            return [f"conv3x3_wgrad_bf16_kernel<WbCfg<{cin}, {cout}, {hw},", ", true>" if cin != cout else ", false>"]      # class is dominated by the res convs)
+        if kind == "fwd":                             # the block's first conv, fused with the max pool
+            return [f"conv_pool_fwd_bf16_kernel<CpCfg<{cin}, {cout}, {hw}>"]
+        return [f"conv3x3_bf16_kernel<BfCfg<{cout}, {cin}, {hw},", "true>, true>" if cin != cout else "true>, false>"]
+    if cin == 3:
+        return ["conv3x3_wgrad_kernel<WgCfg<3, 4, 16, 64"] if kind == "wgrad" else ["conv3x3_kernel<FwdCfg<3, 4, 16, 64"]
     if kind == "wgrad":
-        return f"conv3x3_wgrad_kernel<WgCfg<{cin}, {cin}, {cout}, {hw},"
-    return f"conv3x3_kernel<FwdCfg<{cin}, {cin}, {cout}, {hw}," if kind == "fwd" else f"conv3x3_kernel<FwdCfg<{cout}, {cout}, {cin}, {hw},"
+        return [f"conv3x3_wgrad_kernel<WgCfg<{cin}, {cin}, {cout}, {hw},"]
+    # FwdCfg<CIN, CINP, COUT, HW, TH, TW, NIMG, IN_U8, TRANSW, BFIO>
+    return [f"conv3x3_kernel<FwdCfg<{cin}, {cin}, {cout}, {hw},", "false, false>"] if kind == "fwd" \
+        else [f"conv3x3_kernel<FwdCfg<{cout}, {cout}, {cin}, {hw},", "true, false>"]
 
 
 def pmc_traffic(cls, precision):
@@ -89,18 +98,12 @@ def pmc_traffic(cls, precision):
         tab = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_{precision}.json")))
     except Exception:
         return None
-    key = rocprof_name(cls, precision)
+    keys = rocprof_name(cls, precision)
     for name, v in tab.items():
-        if key not in name:
-            continue
-        if "wgrad" not in cls and "3_16_64" not in cls:
-            args = name[name.index("Cfg<") + 4:name.index(">")].replace(" ", "").split(",")
-            transw = args[6] if "BfCfg" in name else args[8]
-            if (transw == "true") != ("dgrad" in cls):
-                continue
-        return dict(bytes_per_launch=(v["hbm_read_MB_per_call"] + v["hbm_write_MB_per_call"]) * 1048576.0,
-                    read_MB=v["hbm_read_MB_per_call"], write_MB=v["hbm_write_MB_per_call"],
-                    source=f"profiles/r01_pmc_{precision}.json", rocprof_kernel=name)
+        if all(k in name for k in keys):
+            return dict(bytes_per_launch=(v["hbm_read_MB_per_call"] + v["hbm_write_MB_per_call"]) * 1048576.0,
+                        read_MB=v["hbm_read_MB_per_call"], write_MB=v["hbm_write_MB_per_call"],
+                        source=f"profiles/r01_pmc_{precision}.json", rocprof_kernel=name)
     return None
 
 
@@ -223,7 +226,7 @@ def main():
     if rank == 0:
         steps_total = world * T * E * args.steps
         value = steps_total / dt
-        upd = [r for r in prof if r["phase"] == "update" and r["kernel"].startswith("conv")]
+        upd = [r for r in prof if r["phase"] == "update" and r["kernel"].split("_")[0] in ("conv", "resblock")]
         dom = max(upd, key=lambda r: r["ms"]) if upd else None
         roof = None
         if dom is not None:
@@ -231,7 +234,7 @@ def main():
             gbs, tfs = dom["bytes"] / sec / 1e9, dom["flops"] / sec / 1e12
             # matrix peak of the instruction this kernel issues: block1.conv (3 input channels) stays on the fp32 MFMA
             # in both modes; every other conv of the bf16 mode runs v_mfma_f32_16x16x32_bf16
-            on_bf16_mfma = args.precision == "bf16" and ("3_16_64" not in dom["kernel"])
+            on_bf16_mfma = args.precision == "bf16"                   # every conv of the bf16 mode issues v_mfma_f32_16x16x32_bf16
             mpeak = MFMA_BF16_PEAK_TF if on_bf16_mfma else MFMA_F32_PEAK_TF
             f_h, f_m = gbs / HBM_PEAK_GBS, tfs / mpeak
             bound = "mfma" if f_m >= f_h else "hbm"

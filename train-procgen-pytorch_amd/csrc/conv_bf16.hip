@@ -787,7 +787,7 @@ using C1P = C1T<9>;
 __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, const unsigned short* lut16, unsigned short* p_out, uint8_t* p_arg) {
     __shared__ __attribute__((aligned(16))) unsigned short s_in[C1P::NPIX * 4];
     __shared__ __attribute__((aligned(16))) unsigned short s_w[16 * C1_WS];
-    __shared__ __attribute__((aligned(16))) unsigned short s_c[9 * 64 * 16];
+    __shared__ __attribute__((aligned(16))) unsigned short s_c[9 * 64 * 16];       // (a 1.5-pixel stride makes the pooling reads conflict-free but measured slower: 11.3 vs 8.5 ms)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
 #ifdef WG_TIMING
     long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();

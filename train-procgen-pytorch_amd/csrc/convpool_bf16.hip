@@ -4,7 +4,7 @@
 // forward : a work item produces 4 pooled rows of one image from 9 conv rows (one halo row recomputed), which live in
 //           LDS only: the conv output, the largest tensor of the block, is neither written to nor re-read from HBM; the
 //           backward pass needs the pooled arg-max, not the conv output.
-// backward: the gradient of the conv output is never materialised either.  pool_bwd_stage() rebuilds any window of it
+// backward: the gradient of the conv output is never materialised either.  PoolStage (conv_bf16.hip) rebuilds any window of it
 //           in LDS from (pooled gradient, arg-max bytes) for the conv's weight-gradient and data-gradient kernels.
 #include "common.h"
 #include <math.h>
@@ -20,7 +20,9 @@ struct CpCfg {
     static constexpr int CR = 9, PH = CR + 2, PW = HW + 2;           // conv rows per item, staged input rows / cols
     static constexpr int IN_ELEMS = ((PH * PW * S + 7) / 8) * 8;
     static constexpr int NK = (CIN == 32) ? 9 : 5, WS = NK * 32 + 16, W_ELEMS = COUT * WS;
-    static constexpr int SC_ELEMS = CR * HW * COUT;                  // conv-output tile [row][col][channel]
+    static constexpr int SCS = COUT + COUT / 2;                      // conv-output tile pixel stride (elements): 1.5 pixels -> the pooling
+                                                                     // reads (lanes 2 pixels apart) hit every bank once
+    static constexpr int SC_ELEMS = CR * HW * SCS;                   // conv-output tile [row][col][channel]
     static constexpr int NMT = CR * HW / 16, MT = (NMT + 3) / 4, NB = COUT / 16, C8 = CIN / 8;
     static constexpr int NSRC = PH * HW * C8, NLD = (NSRC + 255) / 256;
     static constexpr int IPI = HO / 4;                               // items per image (4 pooled rows each)
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_bf16_kernel(ConvArgs a, uns
                 t = live ? t : C::NMT - 1;
                 const int pl = t * 16 + i, y = pl / C::HW, x = pl % C::HW;
                 abase[mt] = (y * C::PW + x) * C::S;
-                cbase[mt] = live ? pl * C::COUT + kq * 4 : -1;
+                cbase[mt] = live ? pl * C::SCS + kq * 4 : -1;
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_bf16_kernel(ConvArgs a, uns
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int x = 2 * ox - 1 + kx;
-                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * C::HW + (x < 0 ? 0 : x)) * C::COUT + c8 * 8);
+                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * C::HW + (x < 0 ? 0 : x)) * C::SCS + c8 * 8);
                 }
             float best[8];
             unsigned bi[8];

@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
             for (int mt = 0; mt < C::MTC2; ++mt)
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb) {
-                    e_res[mt][nb] = *(const uint2*)(a.x + goff[mt] + nb * 16);          // raw x / dy (L2-resident: just staged)
+                    e_res[mt][nb] = *(const uint2*)(a.x + goff[mt] + nb * 16);          // raw x / dy (staged moments ago; taking dy from its
+                                                                                        // LDS tile instead measured no faster)
                     if (BWD) e_m[mt][nb] = *(const uint2*)(a.m2 + goff[mt] + nb * 16);
                 }
             f32x4 acc[C::MTC2][C::NB];
