@@ -266,11 +266,14 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
             Block& k = c->blk[b];
             k.cin = chan[b]; k.cout = chan[b + 1]; k.hin = hin;
             const size_t X = (size_t)NB * hin * hin * k.cout, p = X / 4;
-            HIPC(dalloc(&k.C, X)); HIPC(dalloc(&k.PI, p));
+            k.C = nullptr;                       // conv output before the pool: bf16 mode keeps it in LDS (fused conv + pool kernels)
+            if (!c->bf) HIPC(dalloc(&k.C, X));
+            HIPC(dalloc(&k.PI, p));
             HIPC(dalloc(&k.P0, p)); HIPC(dalloc(&k.A1, p)); HIPC(dalloc(&k.P1, p)); HIPC(dalloc(&k.A2, p)); HIPC(dalloc(&k.P2, p));
             hin /= 2;
         }
-        HIPC(dalloc(&c->GC, (size_t)NB * 64 * 64 * 16));
+        c->GC = nullptr;                         // gradient of the pre-pool conv output: bf16 mode rebuilds it in LDS (PoolStage)
+        if (!c->bf) HIPC(dalloc(&c->GC, (size_t)NB * 64 * 64 * 16));
         for (int k = 0; k < 3; ++k) HIPC(dalloc(&c->GP[k], (size_t)NB * 32 * 32 * 16));
         c->slab_floats = (size_t)1024 * (32 * 9 * 32 + 32);      // persistent grids never exceed 4 workgroups x 256 CUs
         HIPC(dalloc(&c->slabs, c->slab_floats));
