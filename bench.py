@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
                     help="activation storage: fp32 = parity mode; bf16 = BASELINE config 3 (bf16 storage + bf16 MFMA fwd/dgrad)")
     ap.add_argument("--profile-rollout", action="store_true", help="bracket the rollout-phase launches with HIP events too")
+    ap.add_argument("--no-kernel-profile", action="store_true", help="diagnostic: no HIP events around the launches (roofline = null)")
+    ap.add_argument("--profile-period", type=int, default=4, help="bracket every P-th minibatch update with HIP events (1 = all)")
     ap.add_argument("--h2d", action="store_true", help="also upload the E frames of every rollout step from pinned host memory")
     args = ap.parse_args()
 
@@ -207,7 +209,7 @@ def main():
 
     for it in range(args.warmup):
         iteration(it)
-    eng.profile_enable(2 if args.profile_rollout else 1)
+    eng.profile_enable(0 if args.no_kernel_profile else ((2 if args.profile_rollout else 1) | (max(1, args.profile_period) << 8)))
     eng.profile_read(reset=True)
     fence()
     phase["rollout_s"] = 0.0
@@ -244,7 +246,8 @@ def main():
                         kernel=dom["kernel"], avg_launch_ms=dom["ms"] / dom["launches"], launches=dom["launches"],
                         samples_per_launch=dom["samples"] / dom["launches"], algorithmic_bytes_per_launch=dom["bytes"] / dom["launches"],
                         hbm_GBps=gbs, hbm_frac=f_h, mfma_TFps=tfs, mfma_frac=f_m, mfma_peak_TFps=mpeak,
-                        share_of_timed_region=dom["ms"] / 1e3 / dt)
+                        share_of_timed_region=dom["ms"] * max(1, args.profile_period) / 1e3 / dt,
+                        sampled="HIP events bracket every %d-th minibatch update (same launch sizes in all of them)" % max(1, args.profile_period))
         out = {"metric": "env steps/sec (whole node), coinrun hard-500 IMPALA-CNN PPO", "value": value, "unit": "env steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if args.precision == "bf16" else "f32"), "data": "synthetic",
@@ -254,6 +257,7 @@ def main():
                           "parallelism": f"dp{world} over n_envs"},
                "roofline": roof,
                "phase_ms_per_step": {"rollout": phase["rollout_s"] / args.steps * 1e3, "update": (dt - phase["rollout_s"]) / args.steps * 1e3},
+               "kernel_profile_period": (0 if args.no_kernel_profile else max(1, args.profile_period)),    # kernels[]: the bracketed sample only
                "kernels": sorted(prof, key=lambda r: -r["ms"])[:24],
                "loss_total": summary["Loss/total"]}
         if world == 1 and not args.no_cpu_baseline:

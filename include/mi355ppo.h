@@ -143,7 +143,9 @@ int mi_minibatch_finish(mi_ctx* ctx);      /* multirank only: phase 2 + backward
  *      update phase (phase 1, n = minibatch).  mi_profile_read fills up to max_rows rows of
  *      {class id, phase, launches, total ms, total samples, total algorithmic bytes, total algorithmic flops}
  *      (layer-boundary model of SURVEY.md 8(d)); names via mi_profile_class_name. */
-int mi_profile_enable(mi_ctx* ctx, int32_t enabled);   /* 0 off, 1 update phase only, 2 rollout + update */
+int mi_profile_enable(mi_ctx* ctx, int32_t enabled);   /* low byte: 0 off, 1 update phase only, 2 rollout + update; bits 8.. = P (0 -> 1):
+                                                         * bracket every P-th minibatch of the update phase (sampling keeps the
+                                                         * event records' own cost, ~7 us of stream time per launch, out of the run) */
 int mi_profile_read(mi_ctx* ctx, double* rows7, int32_t max_rows, int32_t* n_rows, int32_t reset);
 const char* mi_profile_class_name(int32_t class_id);
 

@@ -152,6 +152,9 @@ void launch_resblock_bwd_bf16(ConvShape s, const void* dy, const void* a_fwd, co
                               const unsigned short* bank2_t, const unsigned short* bank1_t, hipStream_t st);
 // pre-packed bf16 filter banks: [rows][WS] with WS = NK*32+16, K laid out tap-major (conv_bf16.hip); rows = output
 // channels of the pass (dgrad: transposed + tap-mirrored view).  One descriptor per bank, device-resident.
+// one conv layer's slabs for reduce_all_slabs: [nslab][slab_len] floats at ws + src_off -> grads[w_off..] (first n_w) and grads[b_off..]
+struct SlabDesc { long long src_off, w_off, b_off; int nslab, slab_len, n_w; };
+void launch_reduce_all_slabs(const float* ws, float* grads, const SlabDesc* d_desc, int n_desc, int max_slab_len, hipStream_t st);
 struct BankDesc { long long w_off, out_off; int rows, cin_pass, co_f, ci_f, transw, ws, nk; };
 int  bank_ws(int cin_pass);                 // elements per bank row
 void launch_pack_banks(const float* params, unsigned short* banks, const BankDesc* d_desc, int n_desc, hipStream_t st);

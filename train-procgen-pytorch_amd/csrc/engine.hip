@@ -54,6 +54,8 @@ struct Profiler {
     bool on = false;
     bool all_phases = false;       // false: update phase only (the rollout's ~5.6k tiny launches per iteration are not bracketed)
     int phase = 0;
+    int period = 1, mb_count = 0;  // update phase: bracket every period-th minibatch (two event records per launch cost ~7 us of
+    bool sample_now = true;        // stream time: 11 ms per hard-500 iteration when every launch is bracketed)
     std::vector<ProfPending> pend;
     std::vector<hipEvent_t> pool;
     double ms[2][PC_COUNT] = {};
@@ -91,6 +93,7 @@ struct mi_ctx {
     int64_t wh_off, bh_off;        // heads: (A+1) x H weights, (A+1) bias (device order)
     float *feat, *hout, *dY, *dfeat, *GC, *GP[3];
     float* slabs; size_t slab_floats;
+    long long slab_off[15]; SlabDesc h_slab_desc[15]; SlabDesc* d_slab_desc; int slab_desc_n, slab_desc_cached_n;   // per-layer slab regions; ONE reduce launch per backward pass
     float *gemm_ws, *col_ws, *fs_scratch, *fs_val;
     float* lut;
     unsigned short* lut16;     // uint8 -> bf16(k/255) table (bf16 mode, block1.conv)
@@ -275,8 +278,14 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         c->GC = nullptr;                         // gradient of the pre-pool conv output: bf16 mode rebuilds it in LDS (PoolStage)
         if (!c->bf) HIPC(dalloc(&c->GC, (size_t)NB * 64 * 64 * 16));
         for (int k = 0; k < 3; ++k) HIPC(dalloc(&c->GP[k], (size_t)NB * 32 * 32 * 16));
-        c->slab_floats = (size_t)1024 * (32 * 9 * 32 + 32);      // persistent grids never exceed 4 workgroups x 256 CUs
+        // every conv layer owns a slab region (persistent grids never exceed 4 workgroups x 256 CUs)
+        c->slab_floats = 0;
+        for (size_t l = 0; l < c->convs.size() && l < 15; ++l) {
+            c->slab_off[l] = (long long)c->slab_floats;
+            c->slab_floats += (size_t)1024 * (size_t)(c->convs[l].cout * 9 * c->convs[l].cin + c->convs[l].cout);
+        }
         HIPC(dalloc(&c->slabs, c->slab_floats));
+        HIPC(hipMalloc((void**)&c->d_slab_desc, sizeof(SlabDesc) * 15)); c->slab_desc_n = 0; c->slab_desc_cached_n = -1;
         HIPC(dalloc(&c->fs_scratch, (size_t)128 * 2048));      // FS_GROUPS x 2048 partial column maxima (misc.hip)
     } else {
         c->obs_bytes_per_env = (size_t)cfg->obs_dim * sizeof(float);
@@ -285,7 +294,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         c->mlp_act.resize(c->mlp.size() + 1);
         HIPC(dalloc(&c->mlp_act[0], (size_t)NB * cfg->obs_dim));
         for (size_t l = 0; l < c->mlp.size(); ++l) HIPC(dalloc(&c->mlp_act[l + 1], (size_t)NB * c->mlp[l].out));
-        c->GC = nullptr; c->slabs = nullptr; c->fs_scratch = nullptr;
+        c->GC = nullptr; c->slabs = nullptr; c->fs_scratch = nullptr; c->d_slab_desc = nullptr; c->slab_desc_n = 0; c->slab_desc_cached_n = -1;
         const int wmax = cfg->mlp_width > c->H ? cfg->mlp_width : c->H;
         for (int k = 0; k < 2; ++k) HIPC(dalloc(&c->GP[k], (size_t)NB * wmax));
         c->GP[2] = nullptr;
@@ -372,7 +381,7 @@ int mi_destroy(mi_ctx* c) {
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
     if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc);
-    hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
+    if (c->d_slab_desc) hipFree(c->d_slab_desc); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
@@ -507,7 +516,7 @@ struct ProfScope {
     mi_ctx* c; ProfPending p; bool live;
     // bytes / flops: ALGORITHMIC figures of this launch (layer-boundary model)
     ProfScope(mi_ctx* c_, int cls, long long units, double bytes, double flops)
-        : c(c_), live(c_->prof.on && (c_->prof.all_phases || c_->prof.phase == 1)) {
+        : c(c_), live(c_->prof.on && (c_->prof.phase == 1 ? c_->prof.sample_now : c_->prof.all_phases)) {
         if (!live) return;
         p.a = prof_event(c); p.b = prof_event(c); p.cls = cls; p.phase = c->prof.phase; p.units = units; p.bytes = bytes; p.flops = flops;
         hipEventRecord(p.a, c->stream);
@@ -522,7 +531,8 @@ struct ProfScope {
 int mi_profile_enable(mi_ctx* c, int32_t enabled) {
     ARG(c, "null");
     if (!enabled) prof_harvest(c);
-    c->prof.on = enabled != 0; c->prof.all_phases = enabled == 2;
+    c->prof.on = (enabled & 0xff) != 0; c->prof.all_phases = (enabled & 0xff) == 2;
+    c->prof.period = (enabled >> 8) > 0 ? (enabled >> 8) : 1; c->prof.mb_count = 0; c->prof.sample_now = true;
     return 0;
 }
 const char* mi_profile_class_name(int32_t id) { return (id >= 0 && id < PC_COUNT) ? kProfNames[id] : ""; }
@@ -572,17 +582,31 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
     WgradArgs a{};
     a.pool_arg = pool_arg;
     a.in = src ? src->base : in; a.idx = src ? src->idx : nullptr; a.in_base = src ? src->first : 0;
-    a.dout = dout; a.partial = c->slabs; a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
+    const int layer = (int)(&L - c->convs.data());
+    a.dout = dout; a.partial = c->slabs + c->slab_off[layer]; a.lut = c->lut; a.n = n; a.relu_in = relu_in; a.bf16 = c->bf;
     a.lut16 = c->bf ? c->lut16 : nullptr;
     const int grid = wgrad_grid_for(L.shape, n, c->bf);
     if (grid < 1) return;
-    if ((size_t)grid * (size_t)(L.cout * 9 * L.cin + L.cout) > c->slab_floats) { fprintf(stderr, "mi355ppo: wgrad slab workspace too small\n"); abort(); }
+    if (grid > 1024) { fprintf(stderr, "mi355ppo: wgrad slab workspace too small\n"); abort(); }
     const double px = (double)n * L.hw * L.hw;
     { ProfScope ps(c, PC_CONV_WGRAD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : c->es * L.cin) + (pool_arg ? 0.75 : 1.0) * c->es * L.cout), px * 18.0 * L.cin * L.cout);
       launch_conv_wgrad(L.shape, a, c->stream); }
+    // the slabs of all layers are summed by ONE launch at the end of net_backward (conv_wgrad_reduce_all)
     const int wlen = L.cout * 9 * L.cin;
-    ProfScope ps(c, PC_SLAB_REDUCE, n, 4.0 * grid * (wlen + L.cout), 0.0);
-    launch_reduce_slabs(c->slabs, grid, wlen + L.cout, c->grads + L.w_off, wlen, c->grads + L.b_off, L.cout, c->stream);
+    c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[layer], (long long)L.w_off, (long long)L.b_off, grid, wlen + L.cout, wlen};
+}
+static void conv_wgrad_reduce_all(mi_ctx* c, int n) {
+    if (c->slab_desc_n <= 0) return;
+    int max_len = 0; double bytes = 0;
+    for (int k = 0; k < c->slab_desc_n; ++k) { max_len = std::max(max_len, c->h_slab_desc[k].slab_len); bytes += 4.0 * c->h_slab_desc[k].nslab * c->h_slab_desc[k].slab_len; }
+    // the descriptor table only depends on the batch size: re-uploaded when it changes (pageable source copied at call time)
+    if (c->slab_desc_cached_n != n) {
+        hipMemcpyAsync(c->d_slab_desc, c->h_slab_desc, sizeof(SlabDesc) * c->slab_desc_n, hipMemcpyHostToDevice, c->stream);
+        c->slab_desc_cached_n = n;
+    }
+    { ProfScope ps(c, PC_SLAB_REDUCE, n, bytes, 0.0);
+      launch_reduce_all_slabs(c->slabs, c->grads, c->d_slab_desc, c->slab_desc_n, max_len, c->stream); }
+    c->slab_desc_n = 0;
 }
 
 static void linear_fwd(mi_ctx* c, const float* X, int relu_x, const float* W, const float* b, float* Y, int n, int in, int out, int relu_out, int x_bf16 = 0) {
@@ -777,6 +801,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             conv_dgrad(c, L[0], c->GC, nullptr, nullptr, Gout, n);
         }
     }
+    conv_wgrad_reduce_all(c, n);
 }
 
 // ------------------------------------------------------------------------------------------ predict / forward
@@ -980,6 +1005,7 @@ int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, con
     }
     InputSrc src = minibatch_src(c);
     c->prof.phase = 1;
+    c->prof.sample_now = (c->prof.mb_count++ % c->prof.period) == 0;
     net_forward(c, src, n, false, true, true);
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
     if (impala) launch_fs_metric(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_val, c->stream);
