@@ -232,3 +232,50 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     assert abs(float(a["total"]) - float(b["total"])) < 1e-5 and abs(float(a["xent"]) - float(b["xent"])) < 1e-6
     np.testing.assert_allclose(b["params"], a["params"], rtol=0, atol=2e-6)
     assert np.abs(a["params"] - b["params"]).max() > 0 or True
+
+
+_RCCL_ONE = r'''
+import os, sys
+ROOT, PKG = sys.argv[1], sys.argv[2]
+sys.path[:0] = [ROOT, PKG]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[3], RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import numpy as np, torch, torch.distributed as dist
+from mi355.engine import Engine, PTR_GRADS, PTR_LOSS_STATS
+from mi355.dist import DevicePointerTensor
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)               # backend "nccl" IS RCCL on ROCm: what bench.py --gpus N > 1 does
+ts = torch.cuda.Stream(device=0)
+eng = Engine("impala", 2, 4, 15, 8, stream=ts.cuda_stream, precision="bf16")
+eng.set_multirank(True)
+gp, gn = eng.device_ptr(PTR_GRADS)
+sp, sn = eng.device_ptr(PTR_LOSS_STATS)
+g = DevicePointerTensor(gp, gn).tensor(0)
+s = DevicePointerTensor(sp, sn).tensor(0)
+assert g.is_cuda and g.numel() == eng.n_params and g.data_ptr() == gp
+with torch.cuda.stream(ts):
+    g.fill_(1.5); s.zero_()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM)                 # world 1: identity, but the whole RCCL + stream path runs
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+t = torch.zeros(1, device=dev)
+dist.all_reduce(t)                                           # the max-over-ranks reduction of bench.py
+dist.barrier()
+eng.sync(); torch.cuda.synchronize()
+got = eng.get_grads()
+assert np.all(got == 1.5), got[:4]
+dist.destroy_process_group()
+eng.close()
+print("rccl ok")
+'''
+
+
+def test_rccl_backend_on_engine_buffers_single_rank(tmp_path):
+    """The N > 1 path of bench.py / PPO can only run on a multi-GPU node; what CAN be checked on one GPU is that the
+    RCCL backend initialises, aliases the engine's gradient / loss-stat buffers as torch tensors and all-reduces them
+    on the engine's torch-owned stream (world size 1 = identity, same code path inside torch + RCCL)."""
+    script = tmp_path / "rccl_one.py"
+    script.write_text(_RCCL_ONE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29700 + os.getpid() % 200)
+    r = subprocess.run([sys.executable, str(script), ROOT, PKG, port], env=env, timeout=300, capture_output=True, text=True)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
