@@ -157,6 +157,31 @@ def test_fused_residual_block_bf16(eng, ch, hw, n):
     assert relerr(ga, nhwc(da)) < 1e-2 and relerr(gx, nhwc(dx)) < 1e-2
 
 
+@pytest.mark.parametrize("n", [1, 7])
+def test_residual_block_whole_backward_bf16(eng, n):
+    """16-channel residual block @32x32: data gradients and both weight / bias gradients in ONE launch (the gradient of
+    conv1's output only exists in LDS).  torch reference with the kernel's rounding points: filters bf16 for the data
+    path, d(conv1 output) rounded to bf16 before conv1's transposed conv and weight gradient consume it."""
+    ch, hw = 16, 32
+    g = torch.Generator().manual_seed(77)
+    w1, w2 = torch.randn(ch, ch, 3, 3, generator=g) * 0.15, torch.randn(ch, ch, 3, 3, generator=g) * 0.15
+    x = r16(torch.randn(n, ch, hw, hw, generator=g))
+    a = r16(F.conv2d(F.relu(x), r16(w1), torch.randn(ch, generator=g), padding=1))
+    dy = r16(torch.randn(n, ch, hw, hw, generator=g))
+    da = r16(torch.nn.grad.conv2d_input(a.shape, r16(w2), dy, padding=1) * (a > 0))
+    dx = torch.nn.grad.conv2d_input(x.shape, r16(w1), da, padding=1) * (x > 0) + dy
+    dw2 = torch.nn.grad.conv2d_weight(F.relu(a), w2.shape, dy, padding=1)
+    dw1 = torch.nn.grad.conv2d_weight(F.relu(x), w1.shape, da, padding=1)
+    flat, gx = eng.op_resblock(2, nhwc(dy), w1.numpy(), w2.numpy(), a_fwd=nhwc(a), x_fwd=nhwc(x))
+    flat = flat.ravel()
+    wl = ch * ch * 9
+    assert relerr(gx, nhwc(dx)) < 1e-2
+    assert relerr(flat[:wl].reshape(ch, ch, 3, 3), dw1.numpy()) < 1e-4
+    assert relerr(flat[wl:wl + ch], da.sum(dim=(0, 2, 3)).numpy()) < 1e-4
+    assert relerr(flat[wl + ch:2 * wl + ch].reshape(ch, ch, 3, 3), dw2.numpy()) < 1e-4
+    assert relerr(flat[2 * wl + ch:2 * wl + 2 * ch], dy.sum(dim=(0, 2, 3)).numpy()) < 1e-4
+
+
 @pytest.mark.parametrize("hw,c", [(64, 16), (32, 32), (16, 32)])
 def test_maxpool_bf16(eng, hw, c):
     g = torch.Generator().manual_seed(hw)

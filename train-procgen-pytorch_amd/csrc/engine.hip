@@ -765,6 +765,22 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
                 ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 5, 2.0 * px * 18.0 * ch * ch);
                 launch_resblock_bwd_bf16(l1.shape, dy, a_fwd, x_fwd, da, dx, n, c->banks + l2.bank_d, c->banks + l1.bank_d, c->stream);
             };
+            if (L[1].shape == CS_16_16_32) {
+                // 16 channels @32x32: data gradients AND both weight gradients in one launch (resblock_bwd_full_bf16_kernel);
+                // the gradient of conv1's output never reaches HBM
+                auto rb_full = [&](const ConvLayer& l1, const ConvLayer& l2, const float* dy, const float* a_fwd, const float* x_fwd, float* dx) {
+                    const int grid = resblock_bwd_full_grid(n);
+                    const int i1 = (int)(&l1 - c->convs.data()), i2 = (int)(&l2 - c->convs.data());
+                    { ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 4, 4.0 * px * 18.0 * ch * ch);
+                      launch_resblock_bwd_full_bf16(dy, a_fwd, x_fwd, dx, nullptr, n, c->banks + l2.bank_d, c->banks + l1.bank_d,
+                                                    c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], c->stream); }
+                    const int wlen = l1.cout * 9 * l1.cin;
+                    c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[i2], (long long)l2.w_off, (long long)l2.b_off, grid, wlen + l2.cout, wlen};
+                    c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[i1], (long long)l1.w_off, (long long)l1.b_off, grid, wlen + l1.cout, wlen};
+                };
+                rb_full(L[3], L[4], Gout, k.A2, k.P1, Gb);      // res2: P2 = conv2(relu(A2)) + P1 ; A2 = conv1(relu(P1))
+                rb_full(L[1], L[2], Gb, k.A1, k.P0, Gout);      // res1: P1 = conv2(relu(A1)) + P0 ; A1 = conv1(relu(P0))
+            } else {
             // res2: P2 = conv2(relu(A2)) + P1 ; A2 = conv1(relu(P1))
             rb_bwd(L[3], L[4], Gout, k.A2, k.P1, Ga, Gb);
             conv_wgrad(c, L[4], k.A2, nullptr, 1, Gout, n);
@@ -773,6 +789,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             rb_bwd(L[1], L[2], Gb, k.A1, k.P0, Ga, Gout);
             conv_wgrad(c, L[2], k.A1, nullptr, 1, Gb, n);
             conv_wgrad(c, L[1], k.P0, nullptr, 1, Ga, n);
+            }
         } else {
         // res2: P2 = conv2(relu(A2)) + P1 ; A2 = conv1(relu(P1))
         conv_wgrad(c, L[4], k.A2, nullptr, 1, Gout, n);
@@ -1252,6 +1269,28 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
     launch_pack_banks(dparams, dbanks, ddesc, 2, c->stream);
     if (int r = upload_act(c, x, X, &dx)) return r;
     HIPC(hipMalloc(&doa, X * 2 + 256)); HIPC(hipMalloc(&doy, X * 2 + 256));
+    if (mode == 2) {        // whole backward of a 16-channel block: out_y = dx, out_a[0 .. 2*(9*ch*ch + ch)) = {dW1, db1, dW2, db2} (reference layout)
+        ARG(s == CS_16_16_32 && c->slabs, "the whole-backward kernel exists for the 16-channel blocks @32x32 (IMPALA context)");
+        if (int r = upload_act(c, a_fwd, X, &da)) return r;
+        if (int r = upload_act(c, x_fwd, X, &dxf)) return r;
+        const int grid = resblock_bwd_full_grid(n), slab = (int)wl + ch;
+        float* g = nullptr;
+        HIPC(dalloc(&g, (size_t)2 * slab));
+        float* sl2 = c->slabs; float* sl1 = c->slabs + (size_t)1024 * slab;
+        launch_resblock_bwd_full_bf16(dx, da, dxf, doy, nullptr, n, dbanks, dbanks + bl, sl2, sl1, c->stream);
+        launch_reduce_slabs(sl1, grid, slab, g, (int)wl, g + wl, ch, c->stream);
+        launch_reduce_slabs(sl2, grid, slab, g + slab, (int)wl, g + slab + wl, ch, c->stream);
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(c->stream));
+        std::vector<float> hg(2 * slab);
+        HIPC(hipMemcpy(hg.data(), g, hg.size() * 4, hipMemcpyDeviceToHost));
+        to_ref_layout(td, hg.data(), out_a); memcpy(out_a + wl, hg.data() + wl, ch * 4);
+        to_ref_layout(td, hg.data() + slab, out_a + slab); memcpy(out_a + slab + wl, hg.data() + slab + wl, ch * 4);
+        if (int r = download_act(c, doy, out_y, X)) return r;
+        void* fr2[] = {dparams, dbanks, ddesc, dx, da, dxf, doa, doy, g};
+        for (void* q : fr2) if (q) hipFree(q);
+        return 0;
+    }
     if (mode == 0) {
         launch_resblock_bf16(s, dx, dparams + 2 * wl, dparams + 2 * wl + ch, doa, doy, n, dbanks, dbanks + bl, c->stream);
     } else {

@@ -284,3 +284,240 @@ void launch_resblock_bwd_bf16(ConvShape s, const void* dy, const void* a_fwd, co
         default: break;
     }
 }
+
+// ------------------------------------------------------------------------------------------ whole backward of a residual block
+// Data gradients AND both weight gradients of a residual block in one launch (16-channel blocks @32x32, the largest
+// share of the update's HBM traffic).  Separately, the four kernels move 9.75 tensor passes per block (fused data
+// gradients 5.25 + two weight-gradient kernels 2.25 each); here the tile of every operand is staged once:
+//   reads  dy (12 rows per 8), conv1 output a and block input x (10 rows per 8, ReLU applied while staging)
+//   writes dx only -- the gradient of conv1's output lives in LDS (second transposed conv AND conv1's weight gradient
+//   read it there) and goes to HBM only if the caller asks for it.
+// Weight gradients as in conv3x3_wgrad_bf16_kernel: M = 16 output channels, N = 16 input channels, K = 32 pixels, both
+// operands through ds_read_b64_tr_b16 from the [pixel][channel] tiles, accumulators kept across the persistent loop,
+// waves summed through LDS in fixed order, one slab per workgroup and layer; bias gradients = MFMA against ones.
+// ReLU masks come from the staged relu(a) / relu(x) tiles (> 0 there <=> > 0 before the ReLU).
+typedef short rb_s16x4 __attribute__((ext_vector_type(4)));
+typedef rb_s16x4 __attribute__((address_space(3))) * rb_lds_s16x4_ptr;
+
+struct RbFullArgs {
+    const unsigned short *dy, *a_fwd, *x_fwd;   // bf16 NHWC [n][32][32][16]
+    unsigned short *dx_out, *da_out;            // da_out may be null
+    const unsigned short *bank2_t, *bank1_t;    // transposed banks of conv2 / conv1
+    float *slab2, *slab1;                       // per-workgroup slabs [grid][2304 + 16] of conv2 / conv1
+    int n;
+};
+
+struct RbFull {                                  // C = 16, HW = 32, TH = 8
+    static constexpr int C = 16, HW = 32, TH = 8, S = 16, P = HW + 2, TPI = HW / TH;
+    static constexpr int XR = TH + 4, YR = TH + 2;
+    static constexpr int X_ELEMS = XR * P * S, Y_ELEMS = YR * P * S;
+    static constexpr int NK = 5, WS = NK * 32 + 16, W_ELEMS = C * WS;
+    static constexpr int NMT1 = YR * HW / 16, NMT2 = TH * HW / 16, MT1 = NMT1 / 4, MT2 = NMT2 / 4;     // 20 / 16 tiles: 5 / 4 per wave
+    static constexpr int NX = XR * HW * 2, NA = YR * HW * 2;                                          // 16-byte words staged per tensor
+    static constexpr int KX = (NX + 255) / 256, KA = (NA + 255) / 256;
+    static constexpr int NSTEP = TH * HW / 32;                                                         // 8 pixel steps of 32
+    static constexpr int WLEN = C * 9 * C, SLAB = WLEN + C;
+    static constexpr size_t TILE_BYTES = (size_t)(X_ELEMS + 3 * Y_ELEMS + 2 * W_ELEMS) * 2, RED_BYTES = (size_t)(2 * WLEN + 2 * 4 * C) * 4;
+    static constexpr size_t LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
+};
+
+__global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullArgs a) {
+    using C = RbFull;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_x = smem_h;                         // dy rows ty0-2 .. ty0+TH+1
+    unsigned short* s_y = s_x + C::X_ELEMS;               // d(conv1 output) rows ty0-1 .. ty0+TH
+    unsigned short* s_a = s_y + C::Y_ELEMS;               // relu(conv1 output), same rows
+    unsigned short* s_p = s_a + C::Y_ELEMS;               // relu(block input), same rows
+    unsigned short* s_w1 = s_p + C::Y_ELEMS;              // transposed bank of conv2 (first conv of this pass)
+    unsigned short* s_w2 = s_w1 + C::W_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    for (int e = tid; e < C::W_ELEMS / 8; e += 256) { ((uint4*)s_w1)[e] = ((const uint4*)a.bank2_t)[e]; ((uint4*)s_w2)[e] = ((const uint4*)a.bank1_t)[e]; }
+    for (int e = tid; e < (C::X_ELEMS + 3 * C::Y_ELEMS) / 8; e += 256) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
+    int koff[C::NK];
+#pragma unroll
+    for (int m = 0; m < C::NK; ++m) {
+        int tap = 2 * m + (kq >> 1); const int chunk = kq & 1; if (tap > 8) tap = 8;
+        koff[m] = ((tap / 3) * C::P + (tap % 3)) * C::S + chunk * 8;
+    }
+    f32x4 acc2[9], acc1[9], accb2 = {0.f, 0.f, 0.f, 0.f}, accb1 = {0.f, 0.f, 0.f, 0.f};     // weight-gradient tiles of conv2 / conv1, bias rows
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+
+    const int nwork = a.n * C::TPI;
+    uint4 rx[C::KX], ra[C::KA], rp[C::KA];
+    auto load = [&](int work) {
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+#pragma unroll
+        for (int k = 0; k < C::KX; ++k) {
+            const int e = tid + k * 256;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (e < C::NX) { const int c8 = e & 1, px = (e >> 1) % C::HW, gy = ty0 - 2 + e / (2 * C::HW);
+                             if (gy >= 0 && gy < C::HW) v = *(const uint4*)(a.dy + ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8); }
+            rx[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < C::KA; ++k) {
+            const int e = tid + k * 256;
+            uint4 va = {0u, 0u, 0u, 0u}, vp = {0u, 0u, 0u, 0u};
+            if (e < C::NA) { const int c8 = e & 1, px = (e >> 1) % C::HW, gy = ty0 - 1 + e / (2 * C::HW);
+                             if (gy >= 0 && gy < C::HW) { const long long o = ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8;
+                                                          va = *(const uint4*)(a.a_fwd + o); vp = *(const uint4*)(a.x_fwd + o); } }
+            ra[k] = va; rp[k] = vp;
+        }
+    };
+    if ((int)blockIdx.x < nwork) load(blockIdx.x);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < C::KX; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::NX) *(uint4*)(s_x + ((e / (2 * C::HW)) * C::P + (e >> 1) % C::HW + 1) * C::S + (e & 1) * 8) = rx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < C::KA; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::NA) {
+                const int o = ((e / (2 * C::HW)) * C::P + (e >> 1) % C::HW + 1) * C::S + (e & 1) * 8;
+                *(uint4*)(s_a + o) = (uint4){rb_relu2(ra[k].x), rb_relu2(ra[k].y), rb_relu2(ra[k].z), rb_relu2(ra[k].w)};
+                *(uint4*)(s_p + o) = (uint4){rb_relu2(rp[k].x), rb_relu2(rp[k].y), rb_relu2(rp[k].z), rb_relu2(rp[k].w)};
+            }
+        }
+        __syncthreads();
+        if (work + (int)gridDim.x < nwork) load(work + gridDim.x);
+
+        // ---- da = convT2(dy) * (a > 0) on rows ty0-1 .. ty0+TH -> s_y (rows outside the image: relu(a) is 0 there, so da is 0)
+        {
+            int abase[C::MT1], ybase[C::MT1];
+#pragma unroll
+            for (int mt = 0; mt < C::MT1; ++mt) {
+                const int pl = (wave + 4 * mt) * 16 + i, px = pl % C::HW, ry = pl / C::HW;
+                abase[mt] = (ry * C::P + px) * C::S;
+                ybase[mt] = (ry * C::P + px + 1) * C::S + kq * 4;
+            }
+            f32x4 acc[C::MT1][1];
+            {
+#pragma unroll
+                for (int mt = 0; mt < C::MT1; ++mt) acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const int bbase = i * C::WS + kq * 8;
+#pragma unroll
+                for (int m = 0; m < C::NK; ++m) {
+                    const bf16x8 bv = *(const bf16x8*)(s_w1 + bbase + m * 32);
+#pragma unroll
+                    for (int mt = 0; mt < C::MT1; ++mt) acc[mt][0] = MFMA_BF16(bv, *(const bf16x8*)(s_x + abase[mt] + koff[m]), acc[mt][0]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < C::MT1; ++mt) {
+                const uint2 mk = *(const uint2*)(s_a + ybase[mt]);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rb_lane(mk, r) > 0.f ? acc[mt][0][r] : 0.f;
+                const uint2 raw = rb_pack(v);
+                *(uint2*)(s_y + ybase[mt]) = raw;
+                if (a.da_out) {
+                    const int pl = (wave + 4 * mt) * 16 + i, px = pl % C::HW, ry = pl / C::HW, gy = ty0 - 1 + ry;
+                    if (ry >= 1 && ry <= C::TH) *(uint2*)(a.da_out + ((img * C::HW + gy) * C::HW + px) * C::C + kq * 4) = raw;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dx = convT1(da) * (x > 0) + dy on rows ty0 .. ty0+TH-1 -> HBM
+        {
+            int abase[C::MT2];
+#pragma unroll
+            for (int mt = 0; mt < C::MT2; ++mt) { const int pl = (wave + 4 * mt) * 16 + i; abase[mt] = ((pl / C::HW) * C::P + pl % C::HW) * C::S; }
+            f32x4 acc[C::MT2];
+#pragma unroll
+            for (int mt = 0; mt < C::MT2; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int bbase = i * C::WS + kq * 8;
+#pragma unroll
+            for (int m = 0; m < C::NK; ++m) {
+                const bf16x8 bv = *(const bf16x8*)(s_w2 + bbase + m * 32);
+#pragma unroll
+                for (int mt = 0; mt < C::MT2; ++mt) acc[mt] = MFMA_BF16(bv, *(const bf16x8*)(s_y + abase[mt] + koff[m]), acc[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < C::MT2; ++mt) {
+                const int pl = (wave + 4 * mt) * 16 + i, px = pl % C::HW, oy = pl / C::HW;
+                const uint2 mk = *(const uint2*)(s_p + ((oy + 1) * C::P + px + 1) * C::S + kq * 4);
+                const uint2 sk = *(const uint2*)(s_x + ((oy + 2) * C::P + px + 1) * C::S + kq * 4);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (rb_lane(mk, r) > 0.f ? acc[mt][r] : 0.f) + rb_lane(sk, r);
+                *(uint2*)(a.dx_out + ((img * C::HW + ty0 + oy) * C::HW + px) * C::C + kq * 4) = rb_pack(v);
+            }
+        }
+        // ---- weight gradients: conv2 from (dy, relu(a)), conv1 from (da, relu(x)); pixel steps of 32 dealt to the waves
+        for (int t = wave; t < C::NSTEP; t += 4) {
+            int orow[2];                                   // this lane's two source pixels (interior coordinates), MFMA k permutation as in conv_bf16.hip
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pl = 32 * t + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq;
+                orow[h] = ((pl / C::HW) * C::P + pl % C::HW) * C::S + 4 * cp;
+            }
+            auto tr = [&](const unsigned short* base, int off) {
+                const rb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + orow[0] + off));
+                const rb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + orow[1] + off));
+                return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            const bf16x8 d2 = tr(s_x, (2 * C::P + 1) * C::S);      // dy at the pixel   (s_x row 0 = ty0-2, col 0 = -1)
+            const bf16x8 d1 = tr(s_y, (1 * C::P + 1) * C::S);      // da at the pixel   (s_y row 0 = ty0-1)
+            accb2 = MFMA_BF16(d2, ones, accb2);
+            accb1 = MFMA_BF16(d1, ones, accb1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = ((tap / 3) * C::P + (tap % 3)) * C::S;      // s_a / s_p row 0 = ty0-1, col 0 = -1: tap (0,0) is the pixel's upper-left neighbour
+                acc2[tap] = MFMA_BF16(d2, tr(s_a, toff), acc2[tap]);
+                acc1[tap] = MFMA_BF16(d1, tr(s_p, toff), acc1[tap]);
+            }
+        }
+    }
+    // ---- waves summed through LDS in fixed order; one slab per workgroup and layer
+    __syncthreads();
+    float* red = (float*)smem_h;                              // [2][WLEN] then [2][4][16] bias partials
+    float* redb = red + 2 * C::WLEN;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = ((kq * 4 + r) * 9 + tap) * C::C + i;
+                    red[o] = (w == 0) ? acc2[tap][r] : red[o] + acc2[tap][r];
+                    red[C::WLEN + o] = (w == 0) ? acc1[tap][r] : red[C::WLEN + o] + acc1[tap][r];
+                }
+        }
+        __syncthreads();
+    }
+    if (i == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { redb[wave * 16 + kq * 4 + r] = accb2[r]; redb[64 + wave * 16 + kq * 4 + r] = accb1[r]; }
+    }
+    __syncthreads();
+    float* sl2 = a.slab2 + (long long)blockIdx.x * C::SLAB;
+    float* sl1 = a.slab1 + (long long)blockIdx.x * C::SLAB;
+    for (int e = tid; e < C::WLEN; e += 256) { sl2[e] = red[e]; sl1[e] = red[C::WLEN + e]; }
+    if (tid < 16) {
+        sl2[C::WLEN + tid] = (redb[tid] + redb[16 + tid]) + (redb[32 + tid] + redb[48 + tid]);
+        sl1[C::WLEN + tid] = (redb[64 + tid] + redb[80 + tid]) + (redb[96 + tid] + redb[112 + tid]);
+    }
+}
+int resblock_bwd_full_grid(int n) {
+    int bpc = (int)((160 * 1024) / RbFull::LDS_BYTES);
+    bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
+    const int w = n * RbFull::TPI;
+    return w > 256 * bpc ? 256 * bpc : w;
+}
+// 16-channel residual blocks @32x32 only (CS_16_16_32).  slab2 / slab1: [grid][2320] floats each (grid = resblock_bwd_full_grid(n)).
+void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
+                                   const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)resblock_bwd_full_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbFull::LDS_BYTES); attr = true; }
+    const int grid = resblock_bwd_full_grid(n);
+    if (grid < 1) return;
+    RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
+                 bank2_t, bank1_t, slab2, slab1, n};
+    hipLaunchKernelGGL(resblock_bwd_full_bf16_kernel, dim3(grid), dim3(256), RbFull::LDS_BYTES, st, a);
+}

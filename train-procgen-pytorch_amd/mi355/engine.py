@@ -339,7 +339,8 @@ class Engine:
         return (out, db) if mode in (2, 4) else out
 
     def op_resblock(self, mode, x, w1, w2, b1=None, b2=None, a_fwd=None, x_fwd=None):
-        """bf16 precision: fused residual block.  mode 0 -> (conv1 output, block output); mode 1 (x = dy) -> (d conv1-output, d block-input)."""
+        """bf16 precision: fused residual block.  mode 0 -> (conv1 output, block output); mode 1 (x = dy) -> (d conv1-output, d block-input);
+        mode 2 (16 channels @32x32, x = dy) -> (flat {dW1, db1, dW2, db2} in the head of the first array, d block-input)."""
         x = _f32(x)
         n, hw, _, ch = x.shape
         w1, w2 = _f32(w1), _f32(w2)
