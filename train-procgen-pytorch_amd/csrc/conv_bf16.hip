@@ -88,7 +88,7 @@ struct PoolStage {
                             const unsigned pos = (unsigned)(ky * 3 + kx);
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
-                                if (((ag >> (8 * c)) & 0xffu) == pos) sm[dy * 2 + dx][c] += v[c];
+                                sm[dy * 2 + dx][c] += (((ag >> (8 * c)) & 0xffu) == pos) ? v[c] : 0.f;
                         }
                 }
 #pragma unroll
@@ -862,7 +862,9 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const float v = (q & 1) ? __uint_as_float(w[q >> 1] & 0xffff0000u) : __uint_as_float(w[q >> 1] << 16);
-                        if (valid && (isfirst || v > best[q] || v != v)) { best[q] = v; bi[q] = ky * 3 + kx; }
+                        const bool take = valid & (isfirst | (v > best[q]) | (v != v));      // bitwise: selects, no control flow
+                        best[q] = take ? v : best[q];
+                        bi[q] = take ? (unsigned)(ky * 3 + kx) : bi[q];
                     }
                 }
             const size_t o = ((((size_t)img * 32 + oy0 + oyl) * 32 + ox) * 2 + c8) * 8;
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
                             const unsigned pos = (unsigned)(ky * 3 + kx);
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
-                                if (((ag >> (8 * c)) & 0xffu) == pos) sm[dy * 2 + dx][c] += v[c];
+                                sm[dy * 2 + dx][c] += (((ag >> (8 * c)) & 0xffu) == pos) ? v[c] : 0.f;
                         }
                 }
 #pragma unroll

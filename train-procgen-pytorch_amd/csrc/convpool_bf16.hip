@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_bf16_kernel(ConvArgs a, uns
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const float v = (q & 1) ? __uint_as_float(w[q >> 1] & 0xffff0000u) : __uint_as_float(w[q >> 1] << 16);
-                        if (valid && (isfirst || v > best[q] || v != v)) { best[q] = v; bi[q] = ky * 3 + kx; }
+                        const bool take = valid & (isfirst | (v > best[q]) | (v != v));      // bitwise: selects, no control flow
+                        best[q] = take ? v : best[q];
+                        bi[q] = take ? (unsigned)(ky * 3 + kx) : bi[q];
                     }
                 }
             const size_t o = ((((size_t)img * C::HO + oy0 + oyl) * C::HO + ox) * G8 + c8) * 8;
