@@ -11,6 +11,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------- conv3x3 (NHWC, stride 1, pad 1)
 // One descriptor serves forward and data-gradient launches (dgrad = forward form over dOut with
 // the tap-flipped, channel-transposed weight view; see conv.hip).
+#if defined(__HIPCC__)
+// two fp32 -> one dword of two bf16 (lo in bits 0..15), round to nearest even: ONE v_cvt_pk_bf16_f32 (converting the halves
+// separately costs two converts + and + shift + or)
+typedef float mi_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mi_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned mi_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((mi_f32x2){lo, hi}, mi_bf16x2));
+}
+#endif
+
 struct ConvArgs {
     const void*    in;        // fp32 NHWC [n][HW][HW][CIN]  (or uint8 frames NHWC when the shape is the u8 one)
     const int32_t* idx;       // u8 input only: sample s reads frame idx[s] (minibatch gather); null -> in_base + s

@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_bf16_kernel(ConvArgs a, uns
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb)
                     *(uint2*)(s_c + cbase[mt] + nb * 16) =
-                        (uint2){(unsigned)cp_f2bf(acc[mt][nb][0] + bias_r[nb][0]) | ((unsigned)cp_f2bf(acc[mt][nb][1] + bias_r[nb][1]) << 16),
-                                (unsigned)cp_f2bf(acc[mt][nb][2] + bias_r[nb][2]) | ((unsigned)cp_f2bf(acc[mt][nb][3] + bias_r[nb][3]) << 16)};
+                        (uint2){mi_pk_bf16(acc[mt][nb][0] + bias_r[nb][0], acc[mt][nb][1] + bias_r[nb][1]),
+                                mi_pk_bf16(acc[mt][nb][2] + bias_r[nb][2], acc[mt][nb][3] + bias_r[nb][3])};
             }
         }
         __syncthreads();

@@ -13,7 +13,7 @@ typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ unsigned short fc_f2bf(float x) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
-__device__ __forceinline__ unsigned fc_pack2(float lo, float hi) { return (unsigned)fc_f2bf(lo) | ((unsigned)fc_f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned fc_pack2(float lo, float hi) { return mi_pk_bf16(lo, hi); }
 __device__ __forceinline__ unsigned fc_relu2(unsigned w) { const unsigned neg = (w >> 15) & 0x00010001u; return w & ~(neg * 0xFFFFu); }
 
 __global__ void fc_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, unsigned short* __restrict__ wt, int N, int K) {

@@ -23,7 +23,7 @@ __device__ __forceinline__ float rb_lane(uint2 w, int r) {          // bf16 elem
     return (r & 1) ? __uint_as_float(u & 0xffff0000u) : __uint_as_float(u << 16);
 }
 __device__ __forceinline__ uint2 rb_pack(const float (&v)[4]) {
-    return (uint2){(unsigned)rb_f2bf(v[0]) | ((unsigned)rb_f2bf(v[1]) << 16), (unsigned)rb_f2bf(v[2]) | ((unsigned)rb_f2bf(v[3]) << 16)};
+    return (uint2){mi_pk_bf16(v[0], v[1]), mi_pk_bf16(v[2], v[3])};
 }
 
 template <int C_, int HW_, int TH_, int NIMG_>
