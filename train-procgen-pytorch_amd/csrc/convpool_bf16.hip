@@ -24,6 +24,10 @@ struct CpCfg {
                                                                      // reads (lanes 2 pixels apart) hit every bank once
     static constexpr int SC_ELEMS = CR * HW * SCS;                   // conv-output tile [row][col][channel]
     static constexpr int NMT = CR * HW / 16, MT = (NMT + 3) / 4, NB = COUT / 16, C8 = CIN / 8;
+#ifndef CP_MTC
+#define CP_MTC 3
+#endif
+    static constexpr int MTC = MT < CP_MTC ? MT : CP_MTC;            // M tiles whose accumulators live together
     static constexpr int NSRC = PH * HW * C8, NLD = (NSRC + 255) / 256;
     static constexpr int IPI = HO / 4;                               // items per image (4 pooled rows each)
     static constexpr int NPOOL = 4 * HO * (COUT / 8);                // pooling tasks per item: (row, col, 8-channel group)
@@ -32,7 +36,7 @@ struct CpCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void conv_pool_fwd_bf16_kernel(ConvArgs a, unsigned short* p_out, uint8_t* p_arg) {
+__global__ __launch_bounds__(256, 3) void conv_pool_fwd_bf16_kernel(ConvArgs a, unsigned short* p_out, uint8_t* p_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_in = smem_h;
     unsigned short* s_w = smem_h + C::IN_ELEMS;
@@ -84,14 +88,16 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_bf16_kernel(ConvArgs a, uns
         __syncthreads();
         if (work + (int)gridDim.x < nwork) load(work + gridDim.x);
 
-        // ---- conv: tile t = wave + 4k covers 16 consecutive pixels of the 9 x HW conv rows -> s_c (bf16, + bias)
-        {
-            f32x4 acc[C::MT][C::NB];
-            int abase[C::MT], cbase[C::MT];
+        // ---- conv: tile t = wave + 4k covers 16 consecutive pixels of the 9 x HW conv rows -> s_c (bf16, + bias); tiles in groups
+        // of MTC (accumulators of one group live at a time: 180 -> fewer registers, 3 waves per SIMD)
 #pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt) {
-                int t = wave + 4 * mt;
-                const bool live = t < C::NMT;
+        for (int mt0 = 0; mt0 < C::MT; mt0 += C::MTC) {
+            f32x4 acc[C::MTC][C::NB];
+            int abase[C::MTC], cbase[C::MTC];
+#pragma unroll
+            for (int mt = 0; mt < C::MTC; ++mt) {
+                int t = wave + 4 * (mt0 + mt);
+                const bool live = (mt0 + mt < C::MT) && t < C::NMT;
                 t = live ? t : C::NMT - 1;
                 const int pl = t * 16 + i, y = pl / C::HW, x = pl % C::HW;
                 abase[mt] = (y * C::PW + x) * C::S;
@@ -102,18 +108,20 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_bf16_kernel(ConvArgs a, uns
             const int bbase = i * C::WS + kq * 8;
 #pragma unroll
             for (int m = 0; m < C::NK; ++m) {
-                bf16x8 av[C::MT], bv[C::NB];
+                bf16x8 av[C::MTC], bv[C::NB];
 #pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt) av[mt] = *(const bf16x8*)(s_in + abase[mt] + koff[m]);
+                for (int mt = 0; mt < C::MTC; ++mt) av[mt] = *(const bf16x8*)(s_in + abase[mt] + koff[m]);
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb) bv[nb] = *(const bf16x8*)(s_w + bbase + nb * 16 * C::WS + m * 32);
 #pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt)
+                for (int mt = 0; mt < C::MTC; ++mt)
+                    if (mt0 + mt < C::MT) {
 #pragma unroll
-                    for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);
+                        for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);
+                    }
             }
 #pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt) {
+            for (int mt = 0; mt < C::MTC; ++mt) {
                 if (cbase[mt] < 0) continue;
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb)
