@@ -124,6 +124,12 @@ struct BfCfg {
     static constexpr int C8 = CIN / 8;
     static constexpr int NLD = (NPIX * C8 + 255) / 256;
     static constexpr size_t LDS_BYTES = (size_t)(IN_ELEMS + W_ELEMS) * 2;
+#ifndef BF_WPE_32_16
+#define BF_WPE_32_16 1
+#endif
+    // waves per SIMD the register allocation must leave room for.  The 32-channel 16x16 tiles fit 3 workgroups per CU by LDS
+    // (50.6 KB) but compile to 196 registers = 2 waves per SIMD; forcing 3 spills 76 bytes and measured slower (12.3 vs 10.2 ms)
+    static constexpr int WPE = (CIN == 32 && COUT == 32 && HW == 16 && NIMG == 1) ? BF_WPE_32_16 : 1;
     static_assert(NMT % 4 == 0, "M tiles must split over 4 waves");
 };
 
@@ -169,7 +175,7 @@ __device__ __forceinline__ void bf_tile_store(const uint4 (&r)[C::NLD], unsigned
 // POOLIN (data gradient of a block's first conv): a.in is the POOLED gradient, a.pool_arg the arg-max bytes; the haloed
 // tile of the conv-output gradient is rebuilt in LDS by PoolStage::gather instead of being loaded.
 template <class C, bool POOLIN = false>
-__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, C::WPE) void conv3x3_bf16_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_in = smem_h;
     unsigned short* s_w = smem_h + C::IN_ELEMS;
