@@ -72,6 +72,8 @@ def rocprof_name(cls, precision):
     parts = cls.split("_")
     kind, cin, cout, hw = parts[1], *[int(x) for x in parts[2:5]]
     if parts[0] == "resblock":                        # fused residual block (bf16 mode): RbCfg<C, HW, TH, NIMG>, BWD
+        if kind == "dgrad" and cin == 16:             # 16-channel blocks: data + weight gradients in one kernel
+            return ["resblock_bwd_full_bf16_kernel"]
         return [f"resblock_bf16_kernel<RbCfg<{cin}, {hw},", ", true>" if kind == "dgrad" else ", false>"]
     if precision == "bf16":
         if cin == 3:
@@ -136,7 +138,7 @@ def main():
                     help="activation storage: fp32 = parity mode; bf16 = BASELINE config 3 (bf16 storage + bf16 MFMA fwd/dgrad)")
     ap.add_argument("--profile-rollout", action="store_true", help="bracket the rollout-phase launches with HIP events too")
     ap.add_argument("--no-kernel-profile", action="store_true", help="diagnostic: no HIP events around the launches (roofline = null)")
-    ap.add_argument("--profile-period", type=int, default=4, help="bracket every P-th minibatch update with HIP events (1 = all)")
+    ap.add_argument("--profile-period", type=int, default=8, help="bracket every P-th minibatch update with HIP events (1 = all)")
     ap.add_argument("--h2d", action="store_true", help="also upload the E frames of every rollout step from pinned host memory")
     args = ap.parse_args()
 
