@@ -157,12 +157,13 @@ def test_fused_residual_block_bf16(eng, ch, hw, n):
     assert relerr(ga, nhwc(da)) < 1e-2 and relerr(gx, nhwc(dx)) < 1e-2
 
 
+@pytest.mark.parametrize("ch,hw", [(16, 32), (32, 16)])
 @pytest.mark.parametrize("n", [1, 7])
-def test_residual_block_whole_backward_bf16(eng, n):
-    """16-channel residual block @32x32: data gradients and both weight / bias gradients in ONE launch (the gradient of
-    conv1's output only exists in LDS).  torch reference with the kernel's rounding points: filters bf16 for the data
-    path, d(conv1 output) rounded to bf16 before conv1's transposed conv and weight gradient consume it."""
-    ch, hw = 16, 32
+def test_residual_block_whole_backward_bf16(eng, ch, hw, n):
+    """Residual block (16 channels @32x32, 32 channels @16x16): data gradients and both weight / bias gradients in ONE
+    launch (the gradient of conv1's output only exists in LDS).  torch reference with the kernel's rounding points:
+    filters bf16 for the data path, d(conv1 output) rounded to bf16 before conv1's transposed conv and weight gradient
+    consume it."""
     g = torch.Generator().manual_seed(77)
     w1, w2 = torch.randn(ch, ch, 3, 3, generator=g) * 0.15, torch.randn(ch, ch, 3, 3, generator=g) * 0.15
     x = r16(torch.randn(n, ch, hw, hw, generator=g))

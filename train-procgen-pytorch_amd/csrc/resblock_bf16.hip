@@ -26,9 +26,9 @@ __device__ __forceinline__ uint2 rb_pack(const float (&v)[4]) {
     return (uint2){mi_pk_bf16(v[0], v[1]), mi_pk_bf16(v[2], v[3])};
 }
 
-template <int C_, int HW_, int TH_, int NIMG_>
+template <int C_, int HW_, int TH_, int NIMG_, int NT_ = 256>
 struct RbCfg {
-    static constexpr int C = C_, HW = HW_, TH = TH_, NIMG = NIMG_;
+    static constexpr int C = C_, HW = HW_, TH = TH_, NIMG = NIMG_, NT = NT_, NW = NT_ / 64;      // NT threads = NW waves per workgroup
     static constexpr bool WHOLE = (TH == HW);                // whole images: no halo rows to recompute
     static_assert(WHOLE || NIMG == 1, "row tiles hold one image");
     static_assert(HW % TH == 0, "tiles cover the image");
@@ -41,10 +41,10 @@ struct RbCfg {
     static constexpr int NK = (C == 32) ? 9 : 5, WS = NK * 32 + 16, W_ELEMS = C * WS;
     static constexpr int NB = C / 16, C8 = C / 8;
     static constexpr int NMT1 = NIMG * R1 * HW / 16, NMT2 = NIMG * TH * HW / 16;     // M tiles (16 pixels) of the two convs
-    static constexpr int MT1 = (NMT1 + 3) / 4, MT2 = (NMT2 + 3) / 4;               // per wave (tile t = wave + 4k)
+    static constexpr int MT1 = (NMT1 + NW - 1) / NW, MT2 = (NMT2 + NW - 1) / NW;   // per wave (tile t = wave + NW*k)
     static constexpr int pick(int mt) { return mt % 4 == 0 ? 4 : mt % 3 == 0 ? 3 : mt % 2 == 0 ? 2 : 1; }
     static constexpr int MTC1 = pick(MT1), MTC2 = pick(MT2);   // tiles computed together (bounds the register use)
-    static constexpr int NSRC = NIMG * XR * HW * C8, NLD = (NSRC + 255) / 256;       // 16-byte words staged per item
+    static constexpr int NSRC = NIMG * XR * HW * C8, NLD = (NSRC + NT - 1) / NT;     // 16-byte words staged per item
     static constexpr int TPI = HW / TH;
     static constexpr size_t LDS_BYTES = (size_t)(X_ELEMS + Y_ELEMS + 2 * W_ELEMS) * 2;
     static_assert((NIMG * R1 * HW) % 16 == 0 && (NIMG * TH * HW) % 16 == 0, "whole M tiles");
@@ -84,15 +84,15 @@ __device__ __forceinline__ void rb_conv(const unsigned short* s_src, const unsig
 }
 
 template <class C, bool BWD>
-__global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
+__global__ __launch_bounds__(C::NT) void resblock_bf16_kernel(ResblockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_x = smem_h;                         // staged input (ReLU applied in the forward pass), haloed
     unsigned short* s_y = smem_h + C::X_ELEMS;            // first conv's output after its epilogue, haloed
     unsigned short* s_w1 = s_y + C::Y_ELEMS;
     unsigned short* s_w2 = s_w1 + C::W_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
-    for (int e = tid; e < C::W_ELEMS / 8; e += 256) { ((uint4*)s_w1)[e] = ((const uint4*)a.bank1)[e]; ((uint4*)s_w2)[e] = ((const uint4*)a.bank2)[e]; }
-    for (int e = tid; e < (C::X_ELEMS + C::Y_ELEMS) / 8; e += 256) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
+    for (int e = tid; e < C::W_ELEMS / 8; e += C::NT) { ((uint4*)s_w1)[e] = ((const uint4*)a.bank1)[e]; ((uint4*)s_w2)[e] = ((const uint4*)a.bank2)[e]; }
+    for (int e = tid; e < (C::X_ELEMS + C::Y_ELEMS) / 8; e += C::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
     float b1r[C::NB][4], b2r[C::NB][4];                   // channels nb*16 + 4*kq + r: the accumulator quad of this lane
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
         const int gy0 = C::WHOLE ? -1 : ty0 - 2;
 #pragma unroll
         for (int k = 0; k < C::NLD; ++k) {
-            const int e = tid + k * 256;
+            const int e = tid + k * C::NT;
             uint4 v = {0u, 0u, 0u, 0u};
             if (e < C::NSRC) {
                 const int c8 = e % C::C8, px = (e / C::C8) % C::HW, r = (e / (C::C8 * C::HW)) % C::XR, img = e / (C::C8 * C::HW * C::XR);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
         __syncthreads();                                   // previous item's LDS reads done (and the zero fill, first time)
 #pragma unroll
         for (int k = 0; k < C::NLD; ++k) {
-            const int e = tid + k * 256;
+            const int e = tid + k * C::NT;
             if (e < C::NSRC) {
                 const int c8 = e % C::C8, px = (e / C::C8) % C::HW, rr = e / (C::C8 * C::HW);      // rr = img * XR + r
                 uint4 v = regs[k];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
             bool inimg[C::MTC1], owned[C::MTC1];
 #pragma unroll
             for (int mt = 0; mt < C::MTC1; ++mt) {
-                int t = wave + 4 * (k0 + mt);
+                int t = wave + C::NW * (k0 + mt);
                 const bool live = t < C::NMT1;
                 t = live ? t : C::NMT1 - 1;
                 const int pl = t * 16 + i, px = pl % C::HW, ry = (pl / C::HW) % C::R1, img = pl / (C::HW * C::R1);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
             bool on[C::MTC2];
 #pragma unroll
             for (int mt = 0; mt < C::MTC2; ++mt) {
-                int t = wave + 4 * (k0 + mt);
+                int t = wave + C::NW * (k0 + mt);
                 const bool live = t < C::NMT2;
                 t = live ? t : C::NMT2 - 1;
                 const int pl = t * 16 + i, px = pl % C::HW, oy = (pl / C::HW) % C::TH, img = pl / (C::HW * C::TH);
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256) void resblock_bf16_kernel(ResblockArgs a) {
 
 //                      C  HW  TH NIMG
 using RB_16_32 = RbCfg<16, 32, 16, 1>;      // 53 KB LDS: 3 workgroups per CU
-using RB_32_16 = RbCfg<32, 16, 16, 1>;      // whole image, 101 KB: 1 per CU -- measured faster than 8-row tiles (77 KB, 2 per CU,
-                                            // 25 % halo recompute): 6.3 vs 7.7 ms per iteration forward
+using RB_32_16 = RbCfg<32, 16, 16, 1, 512>; // whole image, 101 KB: ONE workgroup per CU, so it is 512 threads (2 waves per SIMD); 8-row
+                                            // tiles (77 KB, 2 x 256 threads per CU, 25 % halo recompute) measured slower: 7.7 vs 6.3 ms
 using RB_32_8  = RbCfg<32,  8,  8, 2>;      // 70 KB: 2 per CU
 using RB_32_8S = RbCfg<32,  8,  8, 1>;      // rollout-sized batches: one image per workgroup (more workgroups, less serial work each)
 
@@ -255,7 +255,7 @@ static void launch_rb_t(const ResblockArgs& a, hipStream_t st) {
     int grid = C::WHOLE ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
     if (grid > 256 * bpc) grid = 256 * bpc;
     if (grid < 1) return;
-    hipLaunchKernelGGL((resblock_bf16_kernel<C, BWD>), dim3(grid), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((resblock_bf16_kernel<C, BWD>), dim3(grid), dim3(C::NT), C::LDS_BYTES, st, a);
 }
 // shape = the residual convs' ConvShape (CS_16_16_32 / CS_32_32_16 / CS_32_32_8); bank1 / bank2 = forward banks of conv1 / conv2
 void launch_resblock_bf16(ConvShape s, const void* x, const float* b1, const float* b2, void* a_out, void* y_out, int n,
@@ -520,4 +520,228 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
     RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
                  bank2_t, bank1_t, slab2, slab1, n};
     hipLaunchKernelGGL(resblock_bwd_full_bf16_kernel, dim3(grid), dim3(256), RbFull::LDS_BYTES, st, a);
+}
+
+// ------------------------------------------------------------------------------------------ whole backward, 32-channel blocks @16x16
+// Same scheme as resblock_bwd_full_bf16_kernel with the sizes forcing two changes: tiles (72.6 KB) + the two transposed
+// filter banks (39 KB) leave room for ONE workgroup per CU, so the workgroup is 512 threads (8 waves = 2 per SIMD, what two
+// 256-thread workgroups would give); and the 2 x 36 weight-gradient accumulator tiles are dealt to the waves by (tap, input
+// block) column as in the column-split stand-alone kernel: every wave walks all 4 pixel steps with its 2-3 columns of both
+// layers and owns its slab entries outright (no cross-wave reduction).  (A 256-thread variant with the banks streamed from
+// L2 instead of LDS measured 410 us per launch: every K step waited ~0.5 us for its filter fragment.)
+struct RbFull32 {
+    static constexpr int C = 32, HW = 16, TH = 8, S = 48, P = HW + 2, TPI = HW / TH, NW = 8, NT = 512;
+    static constexpr int XR = TH + 4, YR = TH + 2;
+    static constexpr int X_ELEMS = XR * P * S, Y_ELEMS = YR * P * S;
+    static constexpr int NK = 9, WS = NK * 32 + 16, W_ELEMS = C * WS;
+    static constexpr int NMT1 = YR * HW / 16, NMT2 = TH * HW / 16;                                            // 10 / 8 tiles over 8 waves: <= 2 / 1 per wave
+    static constexpr int NX = XR * HW * 4, NA = YR * HW * 4;                                                  // 16-byte words staged per tensor
+    static constexpr int KX = (NX + NT - 1) / NT, KA = (NA + NT - 1) / NT;
+    static constexpr int NSTEP = TH * HW / 32;                                                                 // 4 pixel steps of 32
+    static constexpr int NQ = 18, QMAX = 3;                                                                    // (tap, input block) columns; per wave
+    static constexpr int WLEN = C * 9 * C, SLAB = WLEN + C;
+    static constexpr size_t LDS_BYTES = (size_t)(X_ELEMS + 3 * Y_ELEMS + 2 * W_ELEMS) * 2;
+};
+
+__global__ __launch_bounds__(512) void resblock_bwd_full32_bf16_kernel(RbFullArgs a) {
+    using C = RbFull32;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_x = smem_h;                         // dy rows ty0-2 .. ty0+TH+1
+    unsigned short* s_y = s_x + C::X_ELEMS;               // d(conv1 output) rows ty0-1 .. ty0+TH
+    unsigned short* s_a = s_y + C::Y_ELEMS;               // relu(conv1 output), same rows
+    unsigned short* s_p = s_a + C::Y_ELEMS;               // relu(block input), same rows
+    unsigned short* s_w1 = s_p + C::Y_ELEMS;              // transposed bank of conv2 (first conv of this pass)
+    unsigned short* s_w2 = s_w1 + C::W_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int qcnt = (C::NQ - wv + 7) / 8;                // columns q = wv + 8*qq, qq < qcnt: 3, 3, 2, 2, 2, 2, 2, 2
+    for (int e = tid; e < C::W_ELEMS / 8; e += C::NT) { ((uint4*)s_w1)[e] = ((const uint4*)a.bank2_t)[e]; ((uint4*)s_w2)[e] = ((const uint4*)a.bank1_t)[e]; }
+    for (int e = tid; e < (C::X_ELEMS + 3 * C::Y_ELEMS) / 8; e += C::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
+    int koff[C::NK];
+#pragma unroll
+    for (int m = 0; m < C::NK; ++m) koff[m] = ((m / 3) * C::P + (m % 3)) * C::S + kq * 8;     // 32 channels: one tap per K step, lane quarter = 8-channel chunk
+    f32x4 acc2[C::QMAX][2], acc1[C::QMAX][2], accb[2];                                        // weight-gradient tiles [column][output block]; bias rows (waves 6, 7)
+#pragma unroll
+    for (int q = 0; q < C::QMAX; ++q)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) { acc2[q][cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[q][cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    accb[0] = accb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    const int bbase = i * C::WS + kq * 8;
+
+    const int nwork = a.n * C::TPI;
+    uint4 rx[C::KX], ra[C::KA], rp[C::KA];
+    auto load = [&](int work) {
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+#pragma unroll
+        for (int k = 0; k < C::KX; ++k) {
+            const int e = tid + k * C::NT;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (e < C::NX) { const int c8 = e & 3, px = (e >> 2) % C::HW, gy = ty0 - 2 + e / (4 * C::HW);
+                             if (gy >= 0 && gy < C::HW) v = *(const uint4*)(a.dy + ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8); }
+            rx[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < C::KA; ++k) {
+            const int e = tid + k * C::NT;
+            uint4 va = {0u, 0u, 0u, 0u}, vp = {0u, 0u, 0u, 0u};
+            if (e < C::NA) { const int c8 = e & 3, px = (e >> 2) % C::HW, gy = ty0 - 1 + e / (4 * C::HW);
+                             if (gy >= 0 && gy < C::HW) { const long long o = ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8;
+                                                          va = *(const uint4*)(a.a_fwd + o); vp = *(const uint4*)(a.x_fwd + o); } }
+            ra[k] = va; rp[k] = vp;
+        }
+    };
+    if ((int)blockIdx.x < nwork) load(blockIdx.x);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < C::KX; ++k) {
+            const int e = tid + k * C::NT;
+            if (e < C::NX) *(uint4*)(s_x + ((e / (4 * C::HW)) * C::P + (e >> 2) % C::HW + 1) * C::S + (e & 3) * 8) = rx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < C::KA; ++k) {
+            const int e = tid + k * C::NT;
+            if (e < C::NA) {
+                const int o = ((e / (4 * C::HW)) * C::P + (e >> 2) % C::HW + 1) * C::S + (e & 3) * 8;
+                *(uint4*)(s_a + o) = (uint4){rb_relu2(ra[k].x), rb_relu2(ra[k].y), rb_relu2(ra[k].z), rb_relu2(ra[k].w)};
+                *(uint4*)(s_p + o) = (uint4){rb_relu2(rp[k].x), rb_relu2(rp[k].y), rb_relu2(rp[k].z), rb_relu2(rp[k].w)};
+            }
+        }
+        __syncthreads();
+        if (work + (int)gridDim.x < nwork) load(work + gridDim.x);
+
+        // ---- da = convT2(dy) * (a > 0) on rows ty0-1 .. ty0+TH -> s_y (rows outside the image: relu(a) is 0 there, so da is 0)
+        {
+            const int nmt = (C::NMT1 - wv + 7) / 8;                      // 2, 2, 1, 1, 1, 1, 1, 1
+            int abase[2], ybase[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                int t = wave + 8 * mt; t = t < C::NMT1 ? t : C::NMT1 - 1;
+                const int pl = t * 16 + i, px = pl % C::HW, ry = pl / C::HW;
+                abase[mt] = (ry * C::P + px) * C::S;
+                ybase[mt] = (ry * C::P + px + 1) * C::S + kq * 4;
+            }
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int m = 0; m < C::NK; ++m) {
+                const bf16x8 b0 = *(const bf16x8*)(s_w1 + bbase + m * 32), b1 = *(const bf16x8*)(s_w1 + bbase + 16 * C::WS + m * 32);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    if (mt < nmt) {
+                        const bf16x8 av = *(const bf16x8*)(s_x + abase[mt] + koff[m]);
+                        acc[mt][0] = MFMA_BF16(b0, av, acc[mt][0]);
+                        acc[mt][1] = MFMA_BF16(b1, av, acc[mt][1]);
+                    }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                if (mt < nmt) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const uint2 mk = *(const uint2*)(s_a + ybase[mt] + nb * 16);
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = rb_lane(mk, r) > 0.f ? acc[mt][nb][r] : 0.f;
+                        const uint2 raw = rb_pack(v);
+                        *(uint2*)(s_y + ybase[mt] + nb * 16) = raw;
+                        if (a.da_out) {
+                            const int pl = (wave + 8 * mt) * 16 + i, px = pl % C::HW, ry = pl / C::HW, gy = ty0 - 1 + ry;
+                            if (ry >= 1 && ry <= C::TH) *(uint2*)(a.da_out + ((img * C::HW + gy) * C::HW + px) * C::C + nb * 16 + kq * 4) = raw;
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- dx = convT1(da) * (x > 0) + dy on rows ty0 .. ty0+TH-1 -> HBM: one 16-pixel tile per wave
+        {
+            const int pl = wave * 16 + i, px = pl % C::HW, oy = pl / C::HW;
+            const int abase = (oy * C::P + px) * C::S;
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int m = 0; m < C::NK; ++m) {
+                const bf16x8 av = *(const bf16x8*)(s_y + abase + koff[m]);
+                acc[0] = MFMA_BF16(*(const bf16x8*)(s_w2 + bbase + m * 32), av, acc[0]);
+                acc[1] = MFMA_BF16(*(const bf16x8*)(s_w2 + bbase + 16 * C::WS + m * 32), av, acc[1]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const uint2 mk = *(const uint2*)(s_p + ((oy + 1) * C::P + px + 1) * C::S + nb * 16 + kq * 4);
+                const uint2 sk = *(const uint2*)(s_x + ((oy + 2) * C::P + px + 1) * C::S + nb * 16 + kq * 4);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (rb_lane(mk, r) > 0.f ? acc[nb][r] : 0.f) + rb_lane(sk, r);
+                *(uint2*)(a.dx_out + ((img * C::HW + ty0 + oy) * C::HW + px) * C::C + nb * 16 + kq * 4) = rb_pack(v);
+            }
+        }
+        // ---- weight gradients: conv2 from (dy, relu(a)), conv1 from (da, relu(x)); every wave walks all pixel steps for its columns
+#pragma unroll
+        for (int t = 0; t < C::NSTEP; ++t) {
+            int orow[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pl = 32 * t + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq;
+                orow[h] = ((pl / C::HW) * C::P + pl % C::HW) * C::S + 4 * cp;
+            }
+            auto tr = [&](const unsigned short* base, int off) {
+                const rb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + orow[0] + off));
+                const rb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + orow[1] + off));
+                return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            bf16x8 d2[2], d1[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) { d2[cb] = tr(s_x, (2 * C::P + 1) * C::S + cb * 16); d1[cb] = tr(s_y, (C::P + 1) * C::S + cb * 16); }
+            if (wv == 6) { accb[0] = MFMA_BF16(d2[0], ones, accb[0]); accb[1] = MFMA_BF16(d2[1], ones, accb[1]); }      // bias of conv2
+            if (wv == 7) { accb[0] = MFMA_BF16(d1[0], ones, accb[0]); accb[1] = MFMA_BF16(d1[1], ones, accb[1]); }      // bias of conv1
+#pragma unroll
+            for (int qq = 0; qq < C::QMAX; ++qq)
+                if (qq < qcnt) {                                   // wave-uniform: EXEC stays full for the transpose reads
+                    const int q = wv + 8 * qq, tap = q >> 1, ib = q & 1;
+                    const int toff = ((tap / 3) * C::P + (tap % 3)) * C::S + ib * 16;
+                    const bf16x8 b2 = tr(s_a, toff), b1 = tr(s_p, toff);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) { acc2[qq][cb] = MFMA_BF16(d2[cb], b2, acc2[qq][cb]); acc1[qq][cb] = MFMA_BF16(d1[cb], b1, acc1[qq][cb]); }
+                }
+        }
+    }
+    // ---- every wave owns its columns: straight to the slabs
+    float* sl2 = a.slab2 + (long long)blockIdx.x * C::SLAB;
+    float* sl1 = a.slab1 + (long long)blockIdx.x * C::SLAB;
+#pragma unroll
+    for (int qq = 0; qq < C::QMAX; ++qq)
+        if (qq < qcnt) {
+            const int q = wv + 8 * qq, tap = q >> 1, ib = q & 1;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = ((cb * 16 + kq * 4 + r) * 9 + tap) * C::C + ib * 16 + i;
+                    sl2[o] = acc2[qq][cb][r]; sl1[o] = acc1[qq][cb][r];
+                }
+        }
+    if (i == 0 && wv >= 6) {
+        float* sl = wv == 6 ? sl2 : sl1;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sl[C::WLEN + cb * 16 + kq * 4 + r] = accb[cb][r];
+    }
+}
+int resblock_bwd_full32_grid(int n) {
+    const int w = n * RbFull32::TPI;                      // 111 KB of LDS: one 512-thread workgroup per CU
+    return w > 256 ? 256 : w;
+}
+// 32-channel residual blocks @16x16 (CS_32_32_16).  slab2 / slab1: [grid][9248] floats each (grid = resblock_bwd_full32_grid(n)).
+void launch_resblock_bwd_full32_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
+                                     const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)resblock_bwd_full32_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbFull32::LDS_BYTES); attr = true; }
+    const int grid = resblock_bwd_full32_grid(n);
+    if (grid < 1) return;
+    RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
+                 bank2_t, bank1_t, slab2, slab1, n};
+    hipLaunchKernelGGL(resblock_bwd_full32_bf16_kernel, dim3(grid), dim3(RbFull32::NT), RbFull32::LDS_BYTES, st, a);
 }
