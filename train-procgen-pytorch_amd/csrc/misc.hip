@@ -764,7 +764,6 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
     __shared__ __attribute__((aligned(16))) float s_f[16 * 260];
     __shared__ __attribute__((aligned(16))) float s_w[17 * 260];
     __shared__ float s_z[16 * 17];
-    __shared__ float s_e[16 * 16];
     const int tid = threadIdx.x, e0 = blockIdx.x * 16;
     const int el = tid >> 4, o = tid & 15, e = e0 + el;
     float rwd = 0.f, dn = 0.f;
@@ -797,16 +796,15 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
         s_z[el * 17 + oo] = acc + bh[oo];
     }
     __syncthreads();
+    // the 16 lanes of an env sit in one wave (lane = 16*(el & 3) + o): terms travel by ds_bpermute, no LDS round trips / barriers
     const bool lane_on = o < A;
+    const int gbase = threadIdx.x & 48;                                   // first lane of this env's group inside the wave
     const float z = lane_on ? s_z[el * 17 + o] : 0.f;
-    float mx = s_z[el * 17];
-    for (int k = 1; k < A; ++k) mx = fmaxf(mx, s_z[el * 17 + k]);
+    float mx = __shfl(z, gbase, 64);
+    for (int k = 1; k < A; ++k) mx = fmaxf(mx, __shfl(z, gbase + k, 64));
     auto group_sum = [&](float term) {                    // sum over the env's A lanes, in action order
-        __syncthreads();
-        s_e[el * 16 + o] = term;
-        __syncthreads();
         float t = 0.f;
-        for (int k = 0; k < A; ++k) t += s_e[el * 16 + k];
+        for (int k = 0; k < A; ++k) t += __shfl(term, gbase + k, 64);
         return t;
     };
     const float s1 = group_sum(lane_on ? expf(z - mx) : 0.f);
@@ -814,25 +812,17 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
     const float s2 = group_sum(lane_on ? expf(lp) : 0.f);
     lp -= logf(s2);                                        // Categorical(logits=log_probs) normalises again (policy.py:86-87)
     const float pr = lane_on ? expf(lp) : 0.f;
-    __syncthreads();
-    s_e[el * 16 + o] = pr;
-    __syncthreads();
     float cdf = 0.f;
-    for (int k = 0; k <= o; ++k) cdf += s_e[el * 16 + k];
+    for (int k = 0; k < A; ++k) { const float v = __shfl(pr, gbase + k, 64); cdf += (k <= o) ? v : 0.f; }      // prefix in action order
     const float uu = (e < n) ? (u ? u[e] : philox_uniform(seed, ctr + e)) : 0.f;
     const float mark = (lane_on && cdf <= uu) ? (float)(o + 1) : 0.f;
-    __syncthreads();
-    s_e[el * 16 + o] = mark;
-    __syncthreads();
     float sel = 0.f;
-    for (int k = 0; k < A; ++k) sel = fmaxf(sel, s_e[el * 16 + k]);
+    for (int k = 0; k < A; ++k) sel = fmaxf(sel, __shfl(mark, gbase + k, 64));
     int a_sel = (int)sel;
     if (a_sel > A - 1) a_sel = A - 1;
-    __syncthreads();
-    s_e[el * 16 + o] = lp;
-    __syncthreads();
+    const float lp_pick = __shfl(lp, gbase + a_sel, 64);
     if (o != 0 || e >= n) return;
-    const float lp_sel = s_e[el * 16 + a_sel], val = s_z[el * 17 + A];
+    const float lp_sel = lp_pick, val = s_z[el * 17 + A];
     if (rd) { rew_dst[e] = rwd; done_dst[e] = dn; }        // previous step's reward / done into the (T,E) arrays
     if (act) act[e] = a_sel;
     if (logp) logp[e] = lp_sel;
