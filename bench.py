@@ -74,6 +74,8 @@ def rocprof_name(cls, precision):
     if parts[0] == "resblock":                        # fused residual block (bf16 mode): RbCfg<C, HW, TH, NIMG>, BWD
         if kind == "dgrad" and cin == 16:             # 16-channel blocks: data + weight gradients in one kernel
             return ["resblock_bwd_full_bf16_kernel"]
+        if kind == "dgrad" and hw == 16:              # 32-channel blocks @16x16: likewise (512-thread workgroups)
+            return ["resblock_bwd_full32_bf16_kernel"]
         return [f"resblock_bf16_kernel<RbCfg<{cin}, {hw},", ", true>" if kind == "dgrad" else ", false>"]
     if precision == "bf16":
         if cin == 3:
