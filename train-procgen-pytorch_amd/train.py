@@ -46,6 +46,8 @@ def add_training_args(p):
     p.add_argument('--use_valid_env', action="store_true", default=True)
     p.add_argument('--no-use_valid_env', dest='use_valid_env', action="store_false")
     p.add_argument('--use_wandb', action="store_true")
+    # (new) IMPALA activation storage / matrix-core type: fp32 = the parity mode, bf16 = BASELINE config 3 (what bench.py measures)
+    p.add_argument('--precision', type=str, default=None, choices=['fp32', 'bf16'])
     return p
 
 
@@ -75,7 +77,7 @@ def initialize_model(device, env, hp):
 def train_ppo(args):
     set_global_seeds(args.seed)
     hp = get_hyperparams(args.param_name)
-    for k in ("n_envs", "n_steps", "n_minibatch", "mini_batch_size", "learning_rate", "entropy_coef", "x_entropy_coef"):
+    for k in ("n_envs", "n_steps", "n_minibatch", "mini_batch_size", "learning_rate", "entropy_coef", "x_entropy_coef", "precision"):
         if getattr(args, k, None) is not None:
             hp[k] = getattr(args, k)
     if hp.get("algo", "ppo") != "ppo":
