@@ -156,7 +156,8 @@ int mi_op_conv3x3(mi_ctx* ctx, int32_t mode /*0 fwd,1 dgrad,2 wgrad; a block's f
                   float* out /*fwd/dgrad: activations; wgrad: [cout][cin][3][3]*/, float* dbias_out);
 /* bf16 precision only: the fused residual-block kernels.  mode 0 forward (x, w1, b1, w2, b2 -> out_a = conv1 output,
  * out_y = block output); mode 1 data gradients (x = dy, a_fwd, x_fwd, w1, w2 -> out_a = d conv1-output, out_y = d block-input);
- * mode 2 (16 channels @32x32) the whole backward in one launch: out_y = d block-input, out_a[0 .. 2*(9*ch*ch+ch)) = {dW1, db1, dW2, db2}.
+ * mode 3: res1 + res2 forward in one launch with the same (w1, b1, w2, b2) for both blocks (out_a = second conv1 output);
+ * mode 2 (16 channels @32x32, 32 channels @16x16) the whole backward in one launch: out_y = d block-input, out_a[0 .. 2*(9*ch*ch+ch)) = {dW1, db1, dW2, db2}.
  * Replaces ResidualBlock.forward and its autograd (common/model.py:141-146). */
 int mi_op_resblock(mi_ctx* ctx, int32_t mode, int32_t ch, int32_t hw, int32_t n, const float* x, const float* w1, const float* b1,
                    const float* w2, const float* b2, const float* a_fwd, const float* x_fwd, float* out_a, float* out_y);

@@ -157,6 +157,21 @@ def test_fused_residual_block_bf16(eng, ch, hw, n):
     assert relerr(ga, nhwc(da)) < 1e-2 and relerr(gx, nhwc(dx)) < 1e-2
 
 
+@pytest.mark.parametrize("ch,hw", [(16, 32), (32, 16), (32, 8)])
+@pytest.mark.parametrize("n", [1, 3, 6])
+def test_residual_pair_kernel_equals_two_single_launches(eng, ch, hw, n):
+    """net_forward runs res1 + res2 of a block in ONE launch (res1's output reaches res2 through LDS and registers).  Same
+    arithmetic as two launches of the single-block kernel, so with the same weights for both blocks: bit-identical."""
+    g = torch.Generator().manual_seed(300 + ch + hw)
+    w1, w2 = torch.randn(ch, ch, 3, 3, generator=g) * 0.1, torch.randn(ch, ch, 3, 3, generator=g) * 0.1
+    b1, b2 = torch.randn(ch, generator=g), torch.randn(ch, generator=g)
+    x = nhwc(r16(torch.randn(n, ch, hw, hw, generator=g)))
+    _, y1 = eng.op_resblock(0, x, w1.numpy(), w2.numpy(), b1=b1.numpy(), b2=b2.numpy())
+    a2, y2 = eng.op_resblock(0, y1, w1.numpy(), w2.numpy(), b1=b1.numpy(), b2=b2.numpy())
+    pa, py = eng.op_resblock(3, x, w1.numpy(), w2.numpy(), b1=b1.numpy(), b2=b2.numpy())
+    assert np.array_equal(pa, a2) and np.array_equal(py, y2)
+
+
 @pytest.mark.parametrize("ch,hw", [(16, 32), (32, 16)])
 @pytest.mark.parametrize("n", [1, 7])
 def test_residual_block_whole_backward_bf16(eng, ch, hw, n):

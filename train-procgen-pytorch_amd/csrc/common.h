@@ -164,6 +164,8 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
 int  resblock_bwd_full32_grid(int n);
 void launch_resblock_bwd_full32_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
                                      const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st);
+void launch_resblock_pair_bf16(ConvShape s, const void* x, const float* const* b, void* a1_out, void* y1_out, void* a2_out, void* y2_out, int n,
+                               const unsigned short* const* bank, hipStream_t st);
 void launch_resblock_bwd_bf16(ConvShape s, const void* dy, const void* a_fwd, const void* x_fwd, void* da_out, void* dx_out, int n,
                               const unsigned short* bank2_t, const unsigned short* bank1_t, hipStream_t st);
 // pre-packed bf16 filter banks: [rows][WS] with WS = NK*32+16, K laid out tap-major (conv_bf16.hip); rows = output

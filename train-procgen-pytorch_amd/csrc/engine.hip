@@ -684,15 +684,12 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
             { ProfScope ps(c, PC_POOL_FWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
               if (c->bf) launch_maxpool_fwd_bf16(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); else launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); }
             }
-            if (c->bf) {                     // fused residual blocks; the intermediate is written only when a backward pass follows
+            if (c->bf) {                     // res1 + res2 in ONE launch; intermediates reach HBM only when a backward pass follows
                 const double px = (double)n * L[1].hw * L[1].hw, ch = L[1].cout;
-                for (int r = 0; r < 2; ++r) {
-                    const ConvLayer &l1 = L[1 + 2 * r], &l2 = L[2 + 2 * r];
-                    float* x = r ? k.P1 : k.P0; float* a_out = train ? (r ? k.A2 : k.A1) : nullptr; float* y = r ? k.P2 : k.P1;
-                    ProfScope ps(c, PC_RESBLOCK + (int)l1.shape, n, px * ch * 2.0 * (train ? 3 : 2), 2.0 * px * 18.0 * ch * ch);
-                    launch_resblock_bf16(l1.shape, x, c->params + l1.b_off, c->params + l2.b_off, a_out, y, n,
-                                         c->banks + l1.bank_f, c->banks + l2.bank_f, c->stream);
-                }
+                const float* bb[4] = {c->params + L[1].b_off, c->params + L[2].b_off, c->params + L[3].b_off, c->params + L[4].b_off};
+                const unsigned short* bk[4] = {c->banks + L[1].bank_f, c->banks + L[2].bank_f, c->banks + L[3].bank_f, c->banks + L[4].bank_f};
+                ProfScope ps(c, PC_RESBLOCK + (int)L[1].shape, n, px * ch * 2.0 * (train ? 5 : 2), 4.0 * px * 18.0 * ch * ch);
+                launch_resblock_pair_bf16(L[1].shape, k.P0, bb, train ? k.A1 : nullptr, train ? k.P1 : nullptr, train ? k.A2 : nullptr, k.P2, n, bk, c->stream);
             } else {
                 conv_fwd(c, L[1], k.P0, nullptr, 1, nullptr, k.A1, n);
                 conv_fwd(c, L[2], k.A1, nullptr, 1, k.P0, k.P1, n);
@@ -1264,7 +1261,7 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
                    const float* w2_ref, const float* b2, const float* a_fwd, const float* x_fwd, float* out_a, float* out_y) {
     ARG(c && x && w1_ref && w2_ref && out_a && out_y && n >= 1, "null");
     ARG(c->bf, "the fused residual-block kernels exist in bf16 precision only");
-    ARG(mode == 0 ? (b1 && b2) : (a_fwd && x_fwd), "mode 0 needs the biases, mode 1 the forward tensors");
+    ARG((mode == 0 || mode == 3) ? (b1 && b2) : (a_fwd && x_fwd), "modes 0 / 3 need the biases, modes 1 / 2 the forward tensors");
     ConvShape s;
     if (shape_of(ch, ch, hw, &s)) return -1;
     const size_t X = (size_t)n * hw * hw * ch, wl = (size_t)ch * ch * 9;
@@ -1279,7 +1276,8 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
     const int ws = bank_ws(ch), nk = ch == 32 ? 9 : 5;
     const long long bl = (long long)ch * ws;
     // bank 0 feeds the kernel's first conv, bank 1 its second: forward (w1, w2) as stored; backward (w2^T, w1^T)
-    BankDesc d[2] = {{mode ? (long long)wl : 0, 0, ch, ch, ch, ch, mode ? 1 : 0, ws, nk}, {mode ? 0 : (long long)wl, bl, ch, ch, ch, ch, mode ? 1 : 0, ws, nk}};
+    const bool tr = (mode == 1 || mode == 2);
+    BankDesc d[2] = {{tr ? (long long)wl : 0, 0, ch, ch, ch, ch, tr ? 1 : 0, ws, nk}, {tr ? 0 : (long long)wl, bl, ch, ch, ch, ch, tr ? 1 : 0, ws, nk}};
     HIPC(dalloc(&dbanks, (size_t)2 * bl)); HIPC(hipMalloc((void**)&ddesc, sizeof d)); HIPC(hipMemcpy(ddesc, d, sizeof d, hipMemcpyHostToDevice));
     launch_pack_banks(dparams, dbanks, ddesc, 2, c->stream);
     if (int r = upload_act(c, x, X, &dx)) return r;
@@ -1307,7 +1305,11 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
         for (void* q : fr2) if (q) hipFree(q);
         return 0;
     }
-    if (mode == 0) {
+    if (mode == 3) {        // res1 + res2 in one launch, both with (w1, b1, w2, b2): out_a = second conv1 output, out_y = second block output
+        const float* bb[4] = {dparams + 2 * wl, dparams + 2 * wl + ch, dparams + 2 * wl, dparams + 2 * wl + ch};
+        const unsigned short* bk[4] = {dbanks, dbanks + bl, dbanks, dbanks + bl};
+        launch_resblock_pair_bf16(s, dx, bb, nullptr, nullptr, doa, doy, n, bk, c->stream);
+    } else if (mode == 0) {
         launch_resblock_bf16(s, dx, dparams + 2 * wl, dparams + 2 * wl + ch, doa, doy, n, dbanks, dbanks + bl, c->stream);
     } else {
         if (int r = upload_act(c, a_fwd, X, &da)) return r;

@@ -292,6 +292,157 @@ void launch_resblock_bwd_bf16(ConvShape s, const void* dy, const void* a_fwd, co
     }
 }
 
+// ------------------------------------------------------------------------------------------ both residual blocks of a stage, forward
+// res1 and res2 of an IMPALA block in ONE launch (whole-image configurations only): the output of res1 becomes res2's
+// input through LDS (ReLU applied) and its skip connection through registers, so it is written to HBM once and not read
+// back; the rollout step runs 3 launches for its 6 residual blocks.  Four filter banks stay in LDS.
+struct ResblockPairArgs {
+    const unsigned short* x;                 // block input (pooled map) bf16 NHWC
+    const float* b[4];                       // biases of res1.conv1, res1.conv2, res2.conv1, res2.conv2
+    unsigned short *a1_out, *y1_out, *a2_out, *y2_out;     // conv1 outputs (null in the rollout), res1 output (null in the rollout), res2 output
+    int n;
+    const unsigned short* bank[4];
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairArgs a) {
+    static_assert(C::WHOLE && C::MT1 == C::MTC1 && C::MT2 == C::MTC2, "whole images, one tile group per conv");
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_x = smem_h;
+    unsigned short* s_y = smem_h + C::X_ELEMS;
+    unsigned short* s_w = s_y + C::Y_ELEMS;              // 4 banks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    for (int e = tid; e < C::W_ELEMS / 8; e += C::NT)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) ((uint4*)(s_w + l * C::W_ELEMS))[e] = ((const uint4*)a.bank[l])[e];
+    for (int e = tid; e < (C::X_ELEMS + C::Y_ELEMS) / 8; e += C::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // halos stay zero
+    float* s_b = (float*)(s_w + 4 * C::W_ELEMS);          // the four bias vectors (kept out of the registers: 1024-thread variant is at the 128 limit)
+    for (int e = tid; e < 4 * C::C; e += C::NT) s_b[e] = a.b[e / C::C][e % C::C];
+    int koff[C::NK];
+#pragma unroll
+    for (int m = 0; m < C::NK; ++m) {
+        int tap, chunk;
+        if (C::C == 32) { tap = m; chunk = kq; } else { tap = 2 * m + (kq >> 1); chunk = kq & 1; if (tap > 8) tap = 8; }
+        koff[m] = ((tap / 3) * C::P + (tap % 3)) * C::S + chunk * 8;
+    }
+    const int nwork = (a.n + C::NIMG - 1) / C::NIMG;
+    uint4 regs[C::NLD];
+    auto load = [&](int img0) {
+#pragma unroll
+        for (int k = 0; k < C::NLD; ++k) {
+            const int e = tid + k * C::NT;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (e < C::NSRC) {
+                const int c8 = e % C::C8, px = (e / C::C8) % C::HW, r = (e / (C::C8 * C::HW)) % C::XR, img = e / (C::C8 * C::HW * C::XR);
+                const int gy = r - 1, n = img0 + img;
+                if (n < a.n && gy >= 0 && gy < C::HW) v = *(const uint4*)(a.x + (((long long)n * C::HW + gy) * C::HW + px) * C::C + c8 * 8);
+            }
+            regs[k] = v;
+        }
+    };
+    // tile geometry: whole images, so both convs of both stages use the same pixel tiles (tile k of this wave = wave + NW*k) and the
+    // haloed images s_x / s_y have the same shape: one LDS base + one global offset per tile serve everything
+    static_assert(C::NMT1 == C::NMT2 && C::XR == C::YR, "whole-image geometry");
+    constexpr int CENTER = (C::P + 1) * C::S;            // from a tile pixel's window origin to the pixel itself
+    int abase[C::MT1], poff[C::MT1];                     // window origin in the haloed image; element offset of the pixel's channel quad in the item
+    bool live[C::MT1];
+#pragma unroll
+    for (int mt = 0; mt < C::MT1; ++mt) {
+        int t = wave + C::NW * mt; live[mt] = t < C::NMT1; t = live[mt] ? t : C::NMT1 - 1;
+        const int pl = t * 16 + i, px = pl % C::HW, ry = (pl / C::HW) % C::HW, img = pl / (C::HW * C::HW);
+        abase[mt] = ((img * C::XR + ry) * C::P + px) * C::S;
+        poff[mt] = pl * C::C + kq * 4;
+    }
+    if ((int)blockIdx.x < nwork) load(blockIdx.x * C::NIMG);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int img0 = work * C::NIMG;
+        const long long base = (long long)img0 * C::HW * C::HW * C::C;
+        const int left = a.n - img0;                        // images of this item that exist
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < C::NLD; ++k) {
+            const int e = tid + k * C::NT;
+            if (e < C::NSRC) {
+                const int c8 = e % C::C8, px = (e / C::C8) % C::HW, rr = e / (C::C8 * C::HW);
+                const uint4 v = regs[k];
+                *(uint4*)(s_x + (rr * C::P + px + 1) * C::S + c8 * 8) = (uint4){rb_relu2(v.x), rb_relu2(v.y), rb_relu2(v.z), rb_relu2(v.w)};
+            }
+        }
+        __syncthreads();
+        if (work + (int)gridDim.x < nwork) load((work + gridDim.x) * C::NIMG);
+        uint2 skip[C::MT2][C::NB];                          // skip connection of the current stage (raw values)
+#pragma unroll
+        for (int mt = 0; mt < C::MT2; ++mt) {
+            const bool on = live[mt] && (poff[mt] / (C::HW * C::HW * C::C)) < left;
+#pragma unroll
+            for (int nb = 0; nb < C::NB; ++nb) skip[mt][nb] = on ? *(const uint2*)(a.x + base + poff[mt] + nb * 16) : (uint2){0u, 0u};
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            unsigned short* a_out = st ? a.a2_out : a.a1_out;
+            unsigned short* y_out = st ? a.y2_out : a.y1_out;
+            // ---- conv1 (+ bias) -> a (HBM, optional) and relu(a) -> s_y
+            {
+                f32x4 acc[C::MT1][C::NB];
+                rb_conv<C, C::MT1>(s_x, s_w + (2 * st) * C::W_ELEMS, koff, abase, i, kq, acc);
+#pragma unroll
+                for (int mt = 0; mt < C::MT1; ++mt) {
+                    if (!live[mt]) continue;
+                    const bool on = (poff[mt] / (C::HW * C::HW * C::C)) < left;
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) {
+                        float v[4];
+                        const f32x4 bq = *(const f32x4*)(s_b + (2 * st) * C::C + nb * 16 + kq * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[mt][nb][r] + bq[r];
+                        const uint2 raw = rb_pack(v);
+                        if (a_out && on) *(uint2*)(a_out + base + poff[mt] + nb * 16) = raw;
+                        *(uint2*)(s_y + abase[mt] + CENTER + kq * 4 + nb * 16) = (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- conv2 (+ bias) + skip -> y (HBM; res1's output only when a backward pass follows) and, after res1, relu(y) -> s_x
+            {
+                f32x4 acc[C::MT2][C::NB];
+                rb_conv<C, C::MT2>(s_y, s_w + (2 * st + 1) * C::W_ELEMS, koff, abase, i, kq, acc);
+#pragma unroll
+                for (int mt = 0; mt < C::MT2; ++mt) {
+                    if (!live[mt]) continue;
+                    const bool on = (poff[mt] / (C::HW * C::HW * C::C)) < left;
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb) {
+                        float v[4];
+                        const f32x4 bq = *(const f32x4*)(s_b + (2 * st + 1) * C::C + nb * 16 + kq * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[mt][nb][r] + bq[r] + rb_lane(skip[mt][nb], r);
+                        const uint2 raw = rb_pack(v);
+                        if (y_out && on) *(uint2*)(y_out + base + poff[mt] + nb * 16) = raw;
+                        if (st == 0) {
+                            skip[mt][nb] = raw;                 // res2's skip connection
+                            *(uint2*)(s_x + abase[mt] + CENTER + kq * 4 + nb * 16) = (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};      // res2's conv input
+                        }
+                    }
+                }
+            }
+            if (st == 0) __syncthreads();
+        }
+    }
+}
+
+template <class C>
+static void launch_rbp_t(const ResblockPairArgs& a, hipStream_t st) {
+    constexpr size_t LDS = (size_t)(C::X_ELEMS + C::Y_ELEMS + 4 * C::W_ELEMS) * 2 + 4 * C::C * 4;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)resblock_pair_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    int bpc = (int)((160 * 1024) / LDS);
+    bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
+    int grid = (a.n + C::NIMG - 1) / C::NIMG;
+    if (grid > 256 * bpc) grid = 256 * bpc;
+    if (grid < 1) return;
+    hipLaunchKernelGGL(resblock_pair_bf16_kernel<C>, dim3(grid), dim3(C::NT), LDS, st, a);
+}
+
 // ------------------------------------------------------------------------------------------ whole backward of a residual block
 // Data gradients AND both weight gradients of a residual block in one launch (16-channel blocks @32x32, the largest
 // share of the update's HBM traffic).  Separately, the four kernels move 9.75 tensor passes per block (fused data
@@ -751,4 +902,17 @@ void launch_resblock_bwd_full32_bf16(const void* dy, const void* a_fwd, const vo
     RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
                  bank2_t, bank1_t, slab2, slab1, n};
     hipLaunchKernelGGL(resblock_bwd_full32_bf16_kernel, dim3(grid), dim3(RbFull32::NT), RbFull32::LDS_BYTES, st, a);
+}
+
+// res1 + res2 of a block forward in one launch.  b / bank: res1.conv1, res1.conv2, res2.conv1, res2.conv2 (forward banks).
+void launch_resblock_pair_bf16(ConvShape s, const void* x, const float* const* b, void* a1_out, void* y1_out, void* a2_out, void* y2_out, int n,
+                               const unsigned short* const* bank, hipStream_t st) {
+    ResblockPairArgs a{(const unsigned short*)x, {b[0], b[1], b[2], b[3]}, (unsigned short*)a1_out, (unsigned short*)y1_out, (unsigned short*)a2_out,
+                       (unsigned short*)y2_out, n, {bank[0], bank[1], bank[2], bank[3]}};
+    switch (s) {
+        case CS_16_16_32: launch_rbp_t<RB_16_32>(a, st); break;
+        case CS_32_32_16: launch_rbp_t<RB_32_16>(a, st); break;
+        case CS_32_32_8:  if (n <= 1024) launch_rbp_t<RB_32_8S>(a, st); else launch_rbp_t<RB_32_8>(a, st); break;
+        default: break;
+    }
 }
