@@ -465,21 +465,27 @@ struct RbFullArgs {
     int n;
 };
 
-struct RbFull {                                  // C = 16, HW = 32, TH = 8
-    static constexpr int C = 16, HW = 32, TH = 8, S = 16, P = HW + 2, TPI = HW / TH;
+#ifndef RBFULL_CFG
+#define RBFULL_CFG 8, 256          // tile rows, threads per workgroup (16 rows x 512 threads, 92 KB, one workgroup per CU: 14.8 vs 13.8 ms)
+#endif
+template <int TH_, int NT_>
+struct RbFullT {                                 // C = 16, HW = 32
+    static constexpr int C = 16, HW = 32, TH = TH_, NT = NT_, NW = NT_ / 64, S = 16, P = HW + 2, TPI = HW / TH;
     static constexpr int XR = TH + 4, YR = TH + 2;
     static constexpr int X_ELEMS = XR * P * S, Y_ELEMS = YR * P * S;
     static constexpr int NK = 5, WS = NK * 32 + 16, W_ELEMS = C * WS;
-    static constexpr int NMT1 = YR * HW / 16, NMT2 = TH * HW / 16, MT1 = NMT1 / 4, MT2 = NMT2 / 4;     // 20 / 16 tiles: 5 / 4 per wave
+    static constexpr int NMT1 = YR * HW / 16, NMT2 = TH * HW / 16, MT1 = (NMT1 + NW - 1) / NW, MT2 = NMT2 / NW;     // TH 8 x 4 waves: 20 / 16 tiles = 5 / 4 per wave
+    static_assert(NMT2 % NW == 0, "second conv: whole tiles per wave");
     static constexpr int NX = XR * HW * 2, NA = YR * HW * 2;                                          // 16-byte words staged per tensor
-    static constexpr int KX = (NX + 255) / 256, KA = (NA + 255) / 256;
+    static constexpr int KX = (NX + NT - 1) / NT, KA = (NA + NT - 1) / NT;
     static constexpr int NSTEP = TH * HW / 32;                                                         // 8 pixel steps of 32
     static constexpr int WLEN = C * 9 * C, SLAB = WLEN + C;
-    static constexpr size_t TILE_BYTES = (size_t)(X_ELEMS + 3 * Y_ELEMS + 2 * W_ELEMS) * 2, RED_BYTES = (size_t)(2 * WLEN + 2 * 4 * C) * 4;
+    static constexpr size_t TILE_BYTES = (size_t)(X_ELEMS + 3 * Y_ELEMS + 2 * W_ELEMS) * 2, RED_BYTES = (size_t)(2 * WLEN + 2 * NW * C) * 4;
     static constexpr size_t LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
 };
+using RbFull = RbFullT<RBFULL_CFG>;
 
-__global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullArgs a) {
+__global__ __launch_bounds__(RbFull::NT, 2) void resblock_bwd_full_bf16_kernel(RbFullArgs a) {      // 2 waves per SIMD: <= 256 registers
     using C = RbFull;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_x = smem_h;                         // dy rows ty0-2 .. ty0+TH+1
@@ -489,8 +495,8 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
     unsigned short* s_w1 = s_p + C::Y_ELEMS;              // transposed bank of conv2 (first conv of this pass)
     unsigned short* s_w2 = s_w1 + C::W_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
-    for (int e = tid; e < C::W_ELEMS / 8; e += 256) { ((uint4*)s_w1)[e] = ((const uint4*)a.bank2_t)[e]; ((uint4*)s_w2)[e] = ((const uint4*)a.bank1_t)[e]; }
-    for (int e = tid; e < (C::X_ELEMS + 3 * C::Y_ELEMS) / 8; e += 256) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
+    for (int e = tid; e < C::W_ELEMS / 8; e += C::NT) { ((uint4*)s_w1)[e] = ((const uint4*)a.bank2_t)[e]; ((uint4*)s_w2)[e] = ((const uint4*)a.bank1_t)[e]; }
+    for (int e = tid; e < (C::X_ELEMS + 3 * C::Y_ELEMS) / 8; e += C::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
     int koff[C::NK];
 #pragma unroll
     for (int m = 0; m < C::NK; ++m) {
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
         const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
 #pragma unroll
         for (int k = 0; k < C::KX; ++k) {
-            const int e = tid + k * 256;
+            const int e = tid + k * C::NT;
             uint4 v = {0u, 0u, 0u, 0u};
             if (e < C::NX) { const int c8 = e & 1, px = (e >> 1) % C::HW, gy = ty0 - 2 + e / (2 * C::HW);
                              if (gy >= 0 && gy < C::HW) v = *(const uint4*)(a.dy + ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8); }
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
         }
 #pragma unroll
         for (int k = 0; k < C::KA; ++k) {
-            const int e = tid + k * 256;
+            const int e = tid + k * C::NT;
             uint4 va = {0u, 0u, 0u, 0u}, vp = {0u, 0u, 0u, 0u};
             if (e < C::NA) { const int c8 = e & 1, px = (e >> 1) % C::HW, gy = ty0 - 1 + e / (2 * C::HW);
                              if (gy >= 0 && gy < C::HW) { const long long o = ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8;
@@ -530,12 +536,12 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < C::KX; ++k) {
-            const int e = tid + k * 256;
+            const int e = tid + k * C::NT;
             if (e < C::NX) *(uint4*)(s_x + ((e / (2 * C::HW)) * C::P + (e >> 1) % C::HW + 1) * C::S + (e & 1) * 8) = rx[k];
         }
 #pragma unroll
         for (int k = 0; k < C::KA; ++k) {
-            const int e = tid + k * 256;
+            const int e = tid + k * C::NT;
             if (e < C::NA) {
                 const int o = ((e / (2 * C::HW)) * C::P + (e >> 1) % C::HW + 1) * C::S + (e & 1) * 8;
                 *(uint4*)(s_a + o) = (uint4){rb_relu2(ra[k].x), rb_relu2(ra[k].y), rb_relu2(ra[k].z), rb_relu2(ra[k].w)};
@@ -550,7 +556,8 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
             int abase[C::MT1], ybase[C::MT1];
 #pragma unroll
             for (int mt = 0; mt < C::MT1; ++mt) {
-                const int pl = (wave + 4 * mt) * 16 + i, px = pl % C::HW, ry = pl / C::HW;
+                int t = wave + C::NW * mt; t = t < C::NMT1 ? t : C::NMT1 - 1;          // (a clamped duplicate rewrites the same values)
+                const int pl = t * 16 + i, px = pl % C::HW, ry = pl / C::HW;
                 abase[mt] = (ry * C::P + px) * C::S;
                 ybase[mt] = (ry * C::P + px + 1) * C::S + kq * 4;
             }
@@ -575,7 +582,8 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
                 const uint2 raw = rb_pack(v);
                 *(uint2*)(s_y + ybase[mt]) = raw;
                 if (a.da_out) {
-                    const int pl = (wave + 4 * mt) * 16 + i, px = pl % C::HW, ry = pl / C::HW, gy = ty0 - 1 + ry;
+                    int t = wave + C::NW * mt; t = t < C::NMT1 ? t : C::NMT1 - 1;
+                    const int pl = t * 16 + i, px = pl % C::HW, ry = pl / C::HW, gy = ty0 - 1 + ry;
                     if (ry >= 1 && ry <= C::TH) *(uint2*)(a.da_out + ((img * C::HW + gy) * C::HW + px) * C::C + kq * 4) = raw;
                 }
             }
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
         {
             int abase[C::MT2];
 #pragma unroll
-            for (int mt = 0; mt < C::MT2; ++mt) { const int pl = (wave + 4 * mt) * 16 + i; abase[mt] = ((pl / C::HW) * C::P + pl % C::HW) * C::S; }
+            for (int mt = 0; mt < C::MT2; ++mt) { const int pl = (wave + C::NW * mt) * 16 + i; abase[mt] = ((pl / C::HW) * C::P + pl % C::HW) * C::S; }
             f32x4 acc[C::MT2];
 #pragma unroll
             for (int mt = 0; mt < C::MT2; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
             }
 #pragma unroll
             for (int mt = 0; mt < C::MT2; ++mt) {
-                const int pl = (wave + 4 * mt) * 16 + i, px = pl % C::HW, oy = pl / C::HW;
+                const int pl = (wave + C::NW * mt) * 16 + i, px = pl % C::HW, oy = pl / C::HW;
                 const uint2 mk = *(const uint2*)(s_p + ((oy + 1) * C::P + px + 1) * C::S + kq * 4);
                 const uint2 sk = *(const uint2*)(s_x + ((oy + 2) * C::P + px + 1) * C::S + kq * 4);
                 float v[4];
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
             }
         }
         // ---- weight gradients: conv2 from (dy, relu(a)), conv1 from (da, relu(x)); pixel steps of 32 dealt to the waves
-        for (int t = wave; t < C::NSTEP; t += 4) {
+        for (int t = wave; t < C::NSTEP; t += C::NW) {
             int orow[2];                                   // this lane's two source pixels (interior coordinates), MFMA k permutation as in conv_bf16.hip
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -634,9 +642,9 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
     }
     // ---- waves summed through LDS in fixed order; one slab per workgroup and layer
     __syncthreads();
-    float* red = (float*)smem_h;                              // [2][WLEN] then [2][4][16] bias partials
+    float* red = (float*)smem_h;                              // [2][WLEN] then [2][NW][16] bias partials
     float* redb = red + 2 * C::WLEN;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < C::NW; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
@@ -651,15 +659,16 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_full_bf16_kernel(RbFullAr
     }
     if (i == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { redb[wave * 16 + kq * 4 + r] = accb2[r]; redb[64 + wave * 16 + kq * 4 + r] = accb1[r]; }
+        for (int r = 0; r < 4; ++r) { redb[wave * 16 + kq * 4 + r] = accb2[r]; redb[C::NW * 16 + wave * 16 + kq * 4 + r] = accb1[r]; }
     }
     __syncthreads();
     float* sl2 = a.slab2 + (long long)blockIdx.x * C::SLAB;
     float* sl1 = a.slab1 + (long long)blockIdx.x * C::SLAB;
-    for (int e = tid; e < C::WLEN; e += 256) { sl2[e] = red[e]; sl1[e] = red[C::WLEN + e]; }
+    for (int e = tid; e < C::WLEN; e += C::NT) { sl2[e] = red[e]; sl1[e] = red[C::WLEN + e]; }
     if (tid < 16) {
-        sl2[C::WLEN + tid] = (redb[tid] + redb[16 + tid]) + (redb[32 + tid] + redb[48 + tid]);
-        sl1[C::WLEN + tid] = (redb[64 + tid] + redb[80 + tid]) + (redb[96 + tid] + redb[112 + tid]);
+        float t2 = 0.f, t1 = 0.f;
+        for (int w = 0; w < C::NW; ++w) { t2 += redb[w * 16 + tid]; t1 += redb[C::NW * 16 + w * 16 + tid]; }
+        sl2[C::WLEN + tid] = t2; sl1[C::WLEN + tid] = t1;
     }
 }
 int resblock_bwd_full_grid(int n) {
@@ -677,7 +686,7 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
     if (grid < 1) return;
     RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
                  bank2_t, bank1_t, slab2, slab1, n};
-    hipLaunchKernelGGL(resblock_bwd_full_bf16_kernel, dim3(grid), dim3(256), RbFull::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(resblock_bwd_full_bf16_kernel, dim3(grid), dim3(RbFull::NT), RbFull::LDS_BYTES, st, a);
 }
 
 // ------------------------------------------------------------------------------------------ whole backward, 32-channel blocks @16x16
