@@ -150,7 +150,8 @@ int mi_profile_read(mi_ctx* ctx, double* rows7, int32_t max_rows, int32_t* n_row
 const char* mi_profile_class_name(int32_t class_id);
 
 /* ---- op-level entry points for parity tests (host buffers in, host buffers out; NHWC fp32) */
-int mi_op_conv3x3(mi_ctx* ctx, int32_t mode /*0 fwd,1 dgrad,2 wgrad; a block's first conv, bf16: 3 conv+pool fwd, 4 / 5 wgrad / dgrad from the pooled gradient*/, int32_t cin, int32_t cout, int32_t hw, int32_t n,
+int mi_op_conv3x3(mi_ctx* ctx, int32_t mode /*0 fwd,1 dgrad,2 wgrad; a block's first conv, bf16: 3 conv+pool fwd, 4 / 5 wgrad / dgrad from the pooled gradient,
+                  6 / 7 block2.conv's fused dgrad+wgrad launch returning dW / dx*/, int32_t cin, int32_t cout, int32_t hw, int32_t n,
                   const void* in, int32_t in_is_u8, int32_t relu_in, const float* w_ref /*[cout][cin][3][3]*/,
                   const float* bias, const float* res, const float* mask, const float* dout,
                   float* out /*fwd/dgrad: activations; wgrad: [cout][cin][3][3]*/, float* dbias_out);

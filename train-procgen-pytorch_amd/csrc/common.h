@@ -38,6 +38,8 @@ struct ConvArgs {
     const unsigned short* lut16;   // bf16 mode: 256-entry uint8 -> bf16 table (block1.conv)
     const uint8_t* pool_arg;       // bf16 data gradient of a block's first conv: `in` is the POOLED gradient [n][HW/2][HW/2][C] and these
                                    // are the max-pool arg-max bytes; the conv-output gradient is rebuilt in LDS (pool backward fused)
+    const void*    wg_in;          // with pool_arg (block2.conv): the conv's FORWARD input (bf16 NHWC) -- the kernel then also accumulates
+    float*         wg_partial;     // the weight / bias gradient from the same LDS tile: [grid][cout_f*9*cin_f + cout_f] slabs
 };
 
 struct WgradArgs {
@@ -164,6 +166,7 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
 int  resblock_bwd_full32_grid(int n);
 void launch_resblock_bwd_full32_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
                                      const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st);
+int  conv_bwd_fused_grid(ConvShape s, int n);     // grid (= slab count) of the fused data + weight gradient launch, or -1
 void launch_resblock_pair_bf16(ConvShape s, const void* x, const float* const* b, void* a1_out, void* y1_out, void* a2_out, void* y2_out, int n,
                                const unsigned short* const* bank, hipStream_t st);
 void launch_resblock_bwd_bf16(ConvShape s, const void* dy, const void* a_fwd, const void* x_fwd, void* da_out, void* dx_out, int n,

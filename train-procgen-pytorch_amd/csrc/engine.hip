@@ -817,8 +817,21 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         // max pool, then the block's first conv
         if (b == 0 && c->bf) { conv_wgrad(c, L[0], nullptr, &src, 0, Gout, n, k.PI); break; }     // pool backward fused into the staging
         if (c->bf) {            // blocks 2, 3: both consumers of the conv-output gradient rebuild it from (pooled gradient, arg-max)
-            conv_wgrad(c, L[0], c->blk[b - 1].P2, nullptr, 0, Gout, n, k.PI);
-            conv_dgrad(c, L[0], Gout, nullptr, nullptr, Ga, n, k.PI);
+            const int fgrid = conv_bwd_fused_grid(L[0].shape, n);
+            if (fgrid > 0) {        // block2.conv: data AND weight gradient in one launch (the max-pool backward gather runs once)
+                const int layer = (int)(&L[0] - c->convs.data());
+                ConvArgs a{};
+                a.in = Gout; a.pool_arg = k.PI; a.out = Ga; a.n = n; a.bf16 = 1; a.wbank = c->banks + L[0].bank_d;
+                a.wg_in = c->blk[b - 1].P2; a.wg_partial = c->slabs + c->slab_off[layer];
+                const double px = (double)n * L[0].hw * L[0].hw;
+                { ProfScope ps(c, PC_CONV_DGRAD + (int)L[0].shape, n, px * 2.0 * (2 * L[0].cin + 0.75 * L[0].cout), 2.0 * px * 18.0 * L[0].cin * L[0].cout);
+                  launch_conv_dgrad(L[0].shape, a, c->stream); }
+                const int wlen = L[0].cout * 9 * L[0].cin;
+                c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[layer], (long long)L[0].w_off, (long long)L[0].b_off, fgrid, wlen + L[0].cout, wlen};
+            } else {
+                conv_wgrad(c, L[0], c->blk[b - 1].P2, nullptr, 0, Gout, n, k.PI);
+                conv_dgrad(c, L[0], Gout, nullptr, nullptr, Ga, n, k.PI);
+            }
             std::swap(Gout, Ga);
             continue;
         }
@@ -1169,7 +1182,7 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
     if (mode >= 3) {        // a block's first conv fused with the block's max pool (bf16): 3 = forward -> pooled map,
                             // 4 = weight gradient, 5 = data gradient -- both from the POOLED gradient + the forward's arg-max bytes
         ARG(c->bf && (s == CS_3_16_64 || s == CS_16_32_32 || s == CS_32_32_16), "fused conv+pool modes: block1/2/3.conv in bf16 precision only");
-        ARG(mode <= 5 && !(mode == 5 && s == CS_3_16_64) && in, "mode");
+        ARG(mode <= 7 && !(mode >= 5 && s == CS_3_16_64) && in, "mode");
         const size_t pp = (size_t)n * (hw / 2) * (hw / 2) * cout;
         void *dp = nullptr, *dgi = nullptr; uint8_t* di = nullptr; unsigned short* dbank = nullptr; BankDesc* ddesc = nullptr;
         HIPC(hipMalloc(&dp, pp * 2 + 256)); HIPC(dalloc(&di, pp));
@@ -1204,16 +1217,26 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
             to_ref_layout(td, hg.data(), out);
             if (dbias_out) memcpy(dbias_out, hg.data() + td.n, cout * 4);
             hipFree(g);
-        } else {
+        } else {            // 5: data gradient; 6 / 7: the fused data + weight gradient launch (block2.conv), returning dW (+ db) / dx
             ARG(dout, "dout");
+            ARG(mode == 5 || (conv_bwd_fused_grid(s, n) > 0 && c->slabs), "modes 6 / 7: block2.conv in an IMPALA context");
             if (int r = upload_act(c, dout, pp, &ddout)) return r;
             HIPC(hipMalloc(&dgi, px * cin * 2 + 256));
             ConvArgs g{};
             g.in = ddout; g.pool_arg = di; g.w = dw; g.out = dgi; g.n = n; g.bf16 = 1; g.wbank = dbank + (long long)cout * bank_ws(cin);
+            float* gw = nullptr;
+            if (mode >= 6) { g.wg_in = din; g.wg_partial = c->slabs; HIPC(dalloc(&gw, td.n + cout)); }
             launch_conv_dgrad(s, g, c->stream);
+            if (mode >= 6) launch_reduce_slabs(c->slabs, conv_bwd_fused_grid(s, n), (int)td.n + cout, gw, (int)td.n, gw + td.n, cout, c->stream);
             HIPC(hipGetLastError());
             HIPC(hipStreamSynchronize(c->stream));
-            if (int r = download_act(c, dgi, out, px * cin)) return r;
+            if (mode == 6) {
+                std::vector<float> hg(td.n + cout);
+                HIPC(hipMemcpy(hg.data(), gw, hg.size() * 4, hipMemcpyDeviceToHost));
+                to_ref_layout(td, hg.data(), out);
+                if (dbias_out) memcpy(dbias_out, hg.data() + td.n, cout * 4);
+            } else if (int r = download_act(c, dgi, out, px * cin)) return r;
+            if (gw) hipFree(gw);
         }
         void* fr[] = {dw, db, din, ddout, dp, di, dbank, ddesc, dgi};
         for (void* p : fr) if (p) hipFree(p);

@@ -321,22 +321,23 @@ class Engine:
         is_u8 = inp is not None and inp.dtype == np.uint8
         n = (inp if inp is not None else dout).shape[0]
         # modes: 0 forward, 1 dgrad, 2 wgrad; a block's first conv in bf16 precision also 3 = conv+maxpool forward,
-        # 4 / 5 = weight / data gradient from the POOLED gradient (dout) and the forward's arg-max (inp is needed for it)
+        # 4 / 5 = weight / data gradient from the POOLED gradient (dout) and the forward's arg-max (inp is needed for it);
+        # 6 / 7 = the fused data + weight gradient launch of block2.conv, returning (dW, db) / dx
         inp = None if inp is None else np.ascontiguousarray(inp)
         w_ref = _f32(w_ref)
         bias, res, mask, dout = (None if a is None else _f32(a) for a in (bias, res, mask, dout))
-        if mode in (2, 4):
+        if mode in (2, 4, 6):
             out, db = np.empty((cout, cin, 3, 3), np.float32), np.empty(cout, np.float32)
         elif mode == 3:
             out, db = np.empty((n, hw // 2, hw // 2, cout), np.float32), None
-        elif mode == 5:
+        elif mode in (5, 7):
             out, db = np.empty((n, hw, hw, cin), np.float32), None
         else:
             out, db = np.empty((n, hw, hw, cin if mode == 1 else cout), np.float32), None
         self._chk(self.lib.mi_op_conv3x3(self._ctx, C.c_int32(mode), C.c_int32(cin), C.c_int32(cout), C.c_int32(hw),
                                          C.c_int32(n), _fp(inp), C.c_int32(int(is_u8)), C.c_int32(int(relu_in)), _fp(w_ref),
                                          _fp(bias), _fp(res), _fp(mask), _fp(dout), _fp(out), _fp(db)))
-        return (out, db) if mode in (2, 4) else out
+        return (out, db) if mode in (2, 4, 6) else out
 
     def op_resblock(self, mode, x, w1, w2, b1=None, b2=None, a_fwd=None, x_fwd=None):
         """bf16 precision: fused residual block.  mode 0 -> (conv1 output, block output); mode 1 (x = dy) -> (d conv1-output, d block-input);
