@@ -176,7 +176,7 @@ def test_residual_pair_kernel_equals_two_single_launches(eng, ch, hw, n):
     assert np.array_equal(pa, a2) and np.array_equal(py, y2)
 
 
-@pytest.mark.parametrize("ch,hw", [(16, 32), (32, 16)])
+@pytest.mark.parametrize("ch,hw", [(16, 32), (32, 16), (32, 8)])
 @pytest.mark.parametrize("n", [1, 7])
 def test_residual_block_whole_backward_bf16(eng, ch, hw, n):
     """Residual block (16 channels @32x32, 32 channels @16x16): data gradients and both weight / bias gradients in ONE

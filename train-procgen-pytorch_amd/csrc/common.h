@@ -163,8 +163,8 @@ void launch_resblock_bf16(ConvShape s, const void* x, const float* b1, const flo
 int  resblock_bwd_full_grid(int n);
 void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
                                    const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st);
-int  resblock_bwd_full32_grid(int n);
-void launch_resblock_bwd_full32_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
+int  resblock_bwd_full32_grid(ConvShape s, int n);
+void launch_resblock_bwd_full32_bf16(ConvShape s, const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
                                      const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st);
 int  conv_bwd_fused_grid(ConvShape s, int n);     // grid (= slab count) of the fused data + weight gradient launch, or -1
 void launch_resblock_pair_bf16(ConvShape s, const void* x, const float* const* b, void* a1_out, void* y1_out, void* a2_out, void* y2_out, int n,

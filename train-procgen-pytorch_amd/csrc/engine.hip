@@ -754,14 +754,14 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         const ConvLayer* L = &c->convs[b * 5];
         // fused data gradients where they measured faster than two dgrad launches (16 channels @32x32: 14.5 vs 15.9 ms per
         // iteration; 32 @8x8: equal); at 32 channels @16x16 the two separate launches win (8.3 vs 10.2 ms)
-        if (c->bf && L[1].shape == CS_32_32_16) {
+        if (c->bf && (L[1].shape == CS_32_32_16 || L[1].shape == CS_32_32_8)) {
             // 32 channels @16x16: whole backward of each residual block in one launch (resblock_bwd_full32_bf16_kernel)
             const double px = (double)n * L[1].hw * L[1].hw, ch = L[1].cout;
             auto rb_full32 = [&](const ConvLayer& l1, const ConvLayer& l2, const float* dy, const float* a_fwd, const float* x_fwd, float* dx) {
-                const int grid = resblock_bwd_full32_grid(n);
+                const int grid = resblock_bwd_full32_grid(l1.shape, n);
                 const int i1 = (int)(&l1 - c->convs.data()), i2 = (int)(&l2 - c->convs.data());
                 { ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 4, 4.0 * px * 18.0 * ch * ch);
-                  launch_resblock_bwd_full32_bf16(dy, a_fwd, x_fwd, dx, nullptr, n, c->banks + l2.bank_d, c->banks + l1.bank_d,
+                  launch_resblock_bwd_full32_bf16(l1.shape, dy, a_fwd, x_fwd, dx, nullptr, n, c->banks + l2.bank_d, c->banks + l1.bank_d,
                                                   c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], c->stream); }
                 const int wlen = l1.cout * 9 * l1.cin;
                 c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[i2], (long long)l2.w_off, (long long)l2.b_off, grid, wlen + l2.cout, wlen};
@@ -769,7 +769,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             };
             rb_full32(L[3], L[4], Gout, k.A2, k.P1, Gb);
             rb_full32(L[1], L[2], Gb, k.A1, k.P0, Gout);
-        } else if (c->bf && L[1].shape != CS_32_32_16) {
+        } else if (c->bf) {
             // both data gradients of a residual block in one launch (resblock_bf16.hip): the gradient of conv1's output goes
             // to HBM once (the weight-gradient kernels read it) and to LDS for the second transposed conv
             const double px = (double)n * L[1].hw * L[1].hw, ch = L[1].cout;
@@ -1306,15 +1306,15 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
     if (int r = upload_act(c, x, X, &dx)) return r;
     HIPC(hipMalloc(&doa, X * 2 + 256)); HIPC(hipMalloc(&doy, X * 2 + 256));
     if (mode == 2) {        // whole backward of a 16-channel block: out_y = dx, out_a[0 .. 2*(9*ch*ch + ch)) = {dW1, db1, dW2, db2} (reference layout)
-        ARG((s == CS_16_16_32 || s == CS_32_32_16) && c->slabs, "the whole-backward kernels exist for the 16-channel @32x32 and 32-channel @16x16 blocks (IMPALA context)");
+        ARG((s == CS_16_16_32 || s == CS_32_32_16 || s == CS_32_32_8) && c->slabs, "the whole-backward kernels exist for the 16-channel @32x32 and 32-channel @16x16 blocks (IMPALA context)");
         if (int r = upload_act(c, a_fwd, X, &da)) return r;
         if (int r = upload_act(c, x_fwd, X, &dxf)) return r;
-        const int grid = s == CS_16_16_32 ? resblock_bwd_full_grid(n) : resblock_bwd_full32_grid(n), slab = (int)wl + ch;
+        const int grid = s == CS_16_16_32 ? resblock_bwd_full_grid(n) : resblock_bwd_full32_grid(s, n), slab = (int)wl + ch;
         float* g = nullptr;
         HIPC(dalloc(&g, (size_t)2 * slab));
         float* sl2 = c->slabs; float* sl1 = c->slabs + (size_t)1024 * slab;
         if (s == CS_16_16_32) launch_resblock_bwd_full_bf16(dx, da, dxf, doy, nullptr, n, dbanks, dbanks + bl, sl2, sl1, c->stream);
-        else launch_resblock_bwd_full32_bf16(dx, da, dxf, doy, nullptr, n, dbanks, dbanks + bl, sl2, sl1, c->stream);
+        else launch_resblock_bwd_full32_bf16(s, dx, da, dxf, doy, nullptr, n, dbanks, dbanks + bl, sl2, sl1, c->stream);
         launch_reduce_slabs(sl1, grid, slab, g, (int)wl, g + wl, ch, c->stream);
         launch_reduce_slabs(sl2, grid, slab, g + slab, (int)wl, g + slab + wl, ch, c->stream);
         HIPC(hipGetLastError());

@@ -696,22 +696,26 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
 // block) column as in the column-split stand-alone kernel: every wave walks all 4 pixel steps with its 2-3 columns of both
 // layers and owns its slab entries outright (no cross-wave reduction).  (A 256-thread variant with the banks streamed from
 // L2 instead of LDS measured 410 us per launch: every K step waited ~0.5 us for its filter fragment.)
-struct RbFull32 {
-    static constexpr int C = 32, HW = 16, TH = 8, S = 48, P = HW + 2, TPI = HW / TH, NW = 8, NT = 512;
+template <int HW_, int NT_>
+struct RbFull32T {                               // HW 16: 8-row tiles, 512 threads; HW 8: whole image, 256 threads (79 KB: two per CU)
+    static constexpr int C = 32, HW = HW_, TH = 8, S = 48, P = HW + 2, TPI = HW / TH, NT = NT_, NW = NT_ / 64;
     static constexpr int XR = TH + 4, YR = TH + 2;
     static constexpr int X_ELEMS = XR * P * S, Y_ELEMS = YR * P * S;
     static constexpr int NK = 9, WS = NK * 32 + 16, W_ELEMS = C * WS;
-    static constexpr int NMT1 = YR * HW / 16, NMT2 = TH * HW / 16;                                            // 10 / 8 tiles over 8 waves: <= 2 / 1 per wave
+    static constexpr int NMT1 = YR * HW / 16, NMT2 = TH * HW / 16;                                            // HW 16: 10 / 8 tiles over 8 waves; HW 8: 5 / 4 over 4 waves
+    static_assert(NMT2 == NW && NMT1 <= 2 * NW, "one conv2 tile and at most two conv1 tiles per wave");
     static constexpr int NX = XR * HW * 4, NA = YR * HW * 4;                                                  // 16-byte words staged per tensor
     static constexpr int KX = (NX + NT - 1) / NT, KA = (NA + NT - 1) / NT;
     static constexpr int NSTEP = TH * HW / 32;                                                                 // 4 pixel steps of 32
-    static constexpr int NQ = 18, QMAX = 3;                                                                    // (tap, input block) columns; per wave
+    static constexpr int NQ = 18, QMAX = (NQ + NW - 1) / NW;                                                   // (tap, input block) columns; per wave
     static constexpr int WLEN = C * 9 * C, SLAB = WLEN + C;
     static constexpr size_t LDS_BYTES = (size_t)(X_ELEMS + 3 * Y_ELEMS + 2 * W_ELEMS) * 2;
 };
+using RbFull32 = RbFull32T<16, 512>;
+using RbFull32S = RbFull32T<8, 256>;
 
-__global__ __launch_bounds__(512) void resblock_bwd_full32_bf16_kernel(RbFullArgs a) {
-    using C = RbFull32;
+template <class C>
+__global__ __launch_bounds__(C::NT, C::NT == 256 ? 2 : 1) void resblock_bwd_full32_bf16_kernel(RbFullArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_x = smem_h;                         // dy rows ty0-2 .. ty0+TH+1
     unsigned short* s_y = s_x + C::X_ELEMS;               // d(conv1 output) rows ty0-1 .. ty0+TH
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(512) void resblock_bwd_full32_bf16_kernel(RbFullArg
     unsigned short* s_w2 = s_w1 + C::W_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int qcnt = (C::NQ - wv + 7) / 8;                // columns q = wv + 8*qq, qq < qcnt: 3, 3, 2, 2, 2, 2, 2, 2
+    const int qcnt = (C::NQ - wv + C::NW - 1) / C::NW;    // columns q = wv + NW*qq, qq < qcnt (8 waves: 3, 3, 2, 2, 2, 2, 2, 2)
     for (int e = tid; e < C::W_ELEMS / 8; e += C::NT) { ((uint4*)s_w1)[e] = ((const uint4*)a.bank2_t)[e]; ((uint4*)s_w2)[e] = ((const uint4*)a.bank1_t)[e]; }
     for (int e = tid; e < (C::X_ELEMS + 3 * C::Y_ELEMS) / 8; e += C::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
     int koff[C::NK];
@@ -781,11 +785,11 @@ __global__ __launch_bounds__(512) void resblock_bwd_full32_bf16_kernel(RbFullArg
 
         // ---- da = convT2(dy) * (a > 0) on rows ty0-1 .. ty0+TH -> s_y (rows outside the image: relu(a) is 0 there, so da is 0)
         {
-            const int nmt = (C::NMT1 - wv + 7) / 8;                      // 2, 2, 1, 1, 1, 1, 1, 1
+            const int nmt = (C::NMT1 - wv + C::NW - 1) / C::NW;          // 8 waves: 2, 2, 1, 1, 1, 1, 1, 1
             int abase[2], ybase[2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                int t = wave + 8 * mt; t = t < C::NMT1 ? t : C::NMT1 - 1;
+                int t = wave + C::NW * mt; t = t < C::NMT1 ? t : C::NMT1 - 1;
                 const int pl = t * 16 + i, px = pl % C::HW, ry = pl / C::HW;
                 abase[mt] = (ry * C::P + px) * C::S;
                 ybase[mt] = (ry * C::P + px + 1) * C::S + kq * 4;
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(512) void resblock_bwd_full32_bf16_kernel(RbFullArg
                         const uint2 raw = rb_pack(v);
                         *(uint2*)(s_y + ybase[mt] + nb * 16) = raw;
                         if (a.da_out) {
-                            const int pl = (wave + 8 * mt) * 16 + i, px = pl % C::HW, ry = pl / C::HW, gy = ty0 - 1 + ry;
+                            const int pl = (wave + C::NW * mt) * 16 + i, px = pl % C::HW, ry = pl / C::HW, gy = ty0 - 1 + ry;
                             if (ry >= 1 && ry <= C::TH) *(uint2*)(a.da_out + ((img * C::HW + gy) * C::HW + px) * C::C + nb * 16 + kq * 4) = raw;
                         }
                     }
@@ -861,12 +865,12 @@ __global__ __launch_bounds__(512) void resblock_bwd_full32_bf16_kernel(RbFullArg
             bf16x8 d2[2], d1[2];
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) { d2[cb] = tr(s_x, (2 * C::P + 1) * C::S + cb * 16); d1[cb] = tr(s_y, (C::P + 1) * C::S + cb * 16); }
-            if (wv == 6) { accb[0] = MFMA_BF16(d2[0], ones, accb[0]); accb[1] = MFMA_BF16(d2[1], ones, accb[1]); }      // bias of conv2
-            if (wv == 7) { accb[0] = MFMA_BF16(d1[0], ones, accb[0]); accb[1] = MFMA_BF16(d1[1], ones, accb[1]); }      // bias of conv1
+            if (wv == C::NW - 2) { accb[0] = MFMA_BF16(d2[0], ones, accb[0]); accb[1] = MFMA_BF16(d2[1], ones, accb[1]); }      // bias of conv2
+            if (wv == C::NW - 1) { accb[0] = MFMA_BF16(d1[0], ones, accb[0]); accb[1] = MFMA_BF16(d1[1], ones, accb[1]); }      // bias of conv1
 #pragma unroll
             for (int qq = 0; qq < C::QMAX; ++qq)
                 if (qq < qcnt) {                                   // wave-uniform: EXEC stays full for the transpose reads
-                    const int q = wv + 8 * qq, tap = q >> 1, ib = q & 1;
+                    const int q = wv + C::NW * qq, tap = q >> 1, ib = q & 1;
                     const int toff = ((tap / 3) * C::P + (tap % 3)) * C::S + ib * 16;
                     const bf16x8 b2 = tr(s_a, toff), b1 = tr(s_p, toff);
 #pragma unroll
@@ -880,7 +884,7 @@ __global__ __launch_bounds__(512) void resblock_bwd_full32_bf16_kernel(RbFullArg
 #pragma unroll
     for (int qq = 0; qq < C::QMAX; ++qq)
         if (qq < qcnt) {
-            const int q = wv + 8 * qq, tap = q >> 1, ib = q & 1;
+            const int q = wv + C::NW * qq, tap = q >> 1, ib = q & 1;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -889,28 +893,36 @@ __global__ __launch_bounds__(512) void resblock_bwd_full32_bf16_kernel(RbFullArg
                     sl2[o] = acc2[qq][cb][r]; sl1[o] = acc1[qq][cb][r];
                 }
         }
-    if (i == 0 && wv >= 6) {
-        float* sl = wv == 6 ? sl2 : sl1;
+    if (i == 0 && wv >= C::NW - 2) {
+        float* sl = wv == C::NW - 2 ? sl2 : sl1;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sl[C::WLEN + cb * 16 + kq * 4 + r] = accb[cb][r];
     }
 }
-int resblock_bwd_full32_grid(int n) {
-    const int w = n * RbFull32::TPI;                      // 111 KB of LDS: one 512-thread workgroup per CU
-    return w > 256 ? 256 : w;
+template <class C>
+static int rb_full32_grid_t(int n) {
+    int bpc = (int)((160 * 1024) / C::LDS_BYTES);
+    bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
+    const int w = n * C::TPI;
+    return w > 256 * bpc ? 256 * bpc : w;
 }
-// 32-channel residual blocks @16x16 (CS_32_32_16).  slab2 / slab1: [grid][9248] floats each (grid = resblock_bwd_full32_grid(n)).
-void launch_resblock_bwd_full32_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
-                                     const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st) {
+int resblock_bwd_full32_grid(ConvShape s, int n) { return s == CS_32_32_16 ? rb_full32_grid_t<RbFull32>(n) : s == CS_32_32_8 ? rb_full32_grid_t<RbFull32S>(n) : -1; }
+template <class C>
+static void launch_rb_full32_t(const RbFullArgs& a, hipStream_t st) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)resblock_bwd_full32_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbFull32::LDS_BYTES); attr = true; }
-    const int grid = resblock_bwd_full32_grid(n);
+    if (!attr) { hipFuncSetAttribute((const void*)resblock_bwd_full32_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    const int grid = rb_full32_grid_t<C>(a.n);
     if (grid < 1) return;
+    hipLaunchKernelGGL(resblock_bwd_full32_bf16_kernel<C>, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, a);
+}
+// 32-channel residual blocks @16x16 (CS_32_32_16) and @8x8 (CS_32_32_8).  slab2 / slab1: [grid][9248] floats each.
+void launch_resblock_bwd_full32_bf16(ConvShape s, const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
+                                     const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st) {
     RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
                  bank2_t, bank1_t, slab2, slab1, n};
-    hipLaunchKernelGGL(resblock_bwd_full32_bf16_kernel, dim3(grid), dim3(RbFull32::NT), RbFull32::LDS_BYTES, st, a);
+    if (s == CS_32_32_16) launch_rb_full32_t<RbFull32>(a, st); else if (s == CS_32_32_8) launch_rb_full32_t<RbFull32S>(a, st);
 }
 
 // res1 + res2 of a block forward in one launch.  b / bank: res1.conv1, res1.conv2, res2.conv1, res2.conv2 (forward banks).
