@@ -61,7 +61,11 @@ struct ResblockArgs {
 };
 
 // one 3x3 conv over a haloed LDS image for up to MTC M tiles (pixel tiles whose LDS base offsets are given)
-template <class C, int MTC>
+typedef short rb_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rb_relu2_max(unsigned w) {      // ReLU of two packed bf16 as a signed 16-bit max with 0 (one v_pk_max_i16)
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(rb_s16x2, w), (rb_s16x2){0, 0}));
+}
+template <class C, int MTC, bool RELU_A = false>
 __device__ __forceinline__ void rb_conv(const unsigned short* s_src, const unsigned short* s_w, const int (&koff)[C::NK], const int (&abase)[MTC],
                                         int i, int kq, f32x4 (&acc)[MTC][C::NB]) {
 #pragma unroll
@@ -73,7 +77,13 @@ __device__ __forceinline__ void rb_conv(const unsigned short* s_src, const unsig
     for (int m = 0; m < C::NK; ++m) {
         bf16x8 av[MTC], bv[C::NB];
 #pragma unroll
-        for (int mt = 0; mt < MTC; ++mt) av[mt] = *(const bf16x8*)(s_src + abase[mt] + koff[m]);
+        for (int mt = 0; mt < MTC; ++mt) {
+            av[mt] = *(const bf16x8*)(s_src + abase[mt] + koff[m]);
+            if (RELU_A) {                                   // the image holds raw values (they also serve as the skip connection)
+                const uint4 u = __builtin_bit_cast(uint4, av[mt]);
+                av[mt] = __builtin_bit_cast(bf16x8, (uint4){rb_relu2_max(u.x), rb_relu2_max(u.y), rb_relu2_max(u.z), rb_relu2_max(u.w)});
+            }
+        }
 #pragma unroll
         for (int nb = 0; nb < C::NB; ++nb) bv[nb] = *(const bf16x8*)(s_w + bbase + nb * 16 * C::WS + m * 32);
 #pragma unroll
@@ -294,8 +304,8 @@ void launch_resblock_bwd_bf16(ConvShape s, const void* dy, const void* a_fwd, co
 
 // ------------------------------------------------------------------------------------------ both residual blocks of a stage, forward
 // res1 and res2 of an IMPALA block in ONE launch (whole-image configurations only): the output of res1 becomes res2's
-// input through LDS (ReLU applied) and its skip connection through registers, so it is written to HBM once and not read
-// back; the rollout step runs 3 launches for its 6 residual blocks.  Four filter banks stay in LDS.
+// input through LDS, which holds RAW values: conv1 applies the ReLU on its operand reads (one v_pk_max_i16 per dword) and
+// the skip connection is read back from the same tile, so x is fetched from HBM once and res1's output is never read back; the rollout step runs 3 launches for its 6 residual blocks.  Four filter banks stay in LDS.
 struct ResblockPairArgs {
     const unsigned short* x;                 // block input (pooled map) bf16 NHWC
     const float* b[4];                       // biases of res1.conv1, res1.conv2, res2.conv1, res2.conv2
@@ -365,18 +375,11 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
             if (e < C::NSRC) {
                 const int c8 = e % C::C8, px = (e / C::C8) % C::HW, rr = e / (C::C8 * C::HW);
                 const uint4 v = regs[k];
-                *(uint4*)(s_x + (rr * C::P + px + 1) * C::S + c8 * 8) = (uint4){rb_relu2(v.x), rb_relu2(v.y), rb_relu2(v.z), rb_relu2(v.w)};
+                *(uint4*)(s_x + (rr * C::P + px + 1) * C::S + c8 * 8) = v;      // RAW: conv1 applies the ReLU on its operand reads, the skip reads it back
             }
         }
         __syncthreads();
         if (work + (int)gridDim.x < nwork) load((work + gridDim.x) * C::NIMG);
-        uint2 skip[C::MT2][C::NB];                          // skip connection of the current stage (raw values)
-#pragma unroll
-        for (int mt = 0; mt < C::MT2; ++mt) {
-            const bool on = live[mt] && (poff[mt] / (C::HW * C::HW * C::C)) < left;
-#pragma unroll
-            for (int nb = 0; nb < C::NB; ++nb) skip[mt][nb] = on ? *(const uint2*)(a.x + base + poff[mt] + nb * 16) : (uint2){0u, 0u};
-        }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             unsigned short* a_out = st ? a.a2_out : a.a1_out;
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
             // ---- conv1 (+ bias) -> a (HBM, optional) and relu(a) -> s_y
             {
                 f32x4 acc[C::MT1][C::NB];
-                rb_conv<C, C::MT1>(s_x, s_w + (2 * st) * C::W_ELEMS, koff, abase, i, kq, acc);
+                rb_conv<C, C::MT1, true>(s_x, s_w + (2 * st) * C::W_ELEMS, koff, abase, i, kq, acc);
 #pragma unroll
                 for (int mt = 0; mt < C::MT1; ++mt) {
                     if (!live[mt]) continue;
@@ -414,14 +417,12 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
                     for (int nb = 0; nb < C::NB; ++nb) {
                         float v[4];
                         const f32x4 bq = *(const f32x4*)(s_b + (2 * st + 1) * C::C + nb * 16 + kq * 4);
+                        const uint2 sk = *(const uint2*)(s_x + abase[mt] + CENTER + kq * 4 + nb * 16);      // skip connection: this stage's raw input
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[mt][nb][r] + bq[r] + rb_lane(skip[mt][nb], r);
+                        for (int r = 0; r < 4; ++r) v[r] = acc[mt][nb][r] + bq[r] + rb_lane(sk, r);
                         const uint2 raw = rb_pack(v);
                         if (y_out && on) *(uint2*)(y_out + base + poff[mt] + nb * 16) = raw;
-                        if (st == 0) {
-                            skip[mt][nb] = raw;                 // res2's skip connection
-                            *(uint2*)(s_x + abase[mt] + CENTER + kq * 4 + nb * 16) = (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};      // res2's conv input
-                        }
+                        if (st == 0) *(uint2*)(s_x + abase[mt] + CENTER + kq * 4 + nb * 16) = raw;      // res2's input (raw: conv operand ReLU'd on read, skip as is)
                     }
                 }
             }
