@@ -111,6 +111,28 @@ def pmc_traffic(cls, precision):
     return None
 
 
+# Tensor passes the FUSED bf16 kernels really move, as a fraction of the SURVEY 8(d) layer-boundary bytes they are priced at
+# (the model charges every conv / pool boundary; fusion keeps those tensors in LDS).  Used for the `own_*` fields only.
+OWN_TRAFFIC = {
+    "resblock_dgrad": 4.0 / 7.0,          # whole backward of a residual block: dy, a, x in; dx out   vs 2 x 3p + p
+    "resblock_fwd": 5.0 / 10.0,           # res1 + res2: x in; a1, y1, a2, y2 out                    vs 2 x (2 x 2p + p)
+    "conv_fwd_3_16_64": 61440.0 / 307200.0,           # frames in, pooled map + arg-max out             vs I + 2X + p
+    "conv_wgrad_3_16_64": 61440.0 / 438272.0,         # frames, pooled gradient + arg-max in            vs I + 3X + p
+    "conv_fwd_16_32_32": 57344.0 / 180224.0,
+    "conv_dgrad_16_32_32": 90112.0 / 278528.0,        # block2.conv data + weight gradient from the pooled gradient
+    "conv_fwd_32_32_16": 22528.0 / 53248.0,
+}
+
+
+def own_traffic_ratio(cls, precision):
+    if precision != "bf16":
+        return 1.0
+    for k, v in OWN_TRAFFIC.items():
+        if cls.startswith(k):
+            return v
+    return 1.0
+
+
 def host_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a 1-GPU box exposes all
     host CPUs but grants a 16-core share); oversubscribing the quota makes the CPU leg slower, not faster."""
@@ -250,6 +272,9 @@ def main():
                         kernel=dom["kernel"], avg_launch_ms=dom["ms"] / dom["launches"], launches=dom["launches"],
                         samples_per_launch=dom["samples"] / dom["launches"], algorithmic_bytes_per_launch=dom["bytes"] / dom["launches"],
                         hbm_GBps=gbs, hbm_frac=f_h, mfma_TFps=tfs, mfma_frac=f_m, mfma_peak_TFps=mpeak,
+                        model="algorithmic bytes = SURVEY 8(d) layer-boundary model (a fused kernel can exceed 100 % of it)",
+                        own_min_bytes_per_launch=dom["bytes"] / dom["launches"] * own_traffic_ratio(dom["kernel"], args.precision),
+                        own_hbm_frac=f_h * own_traffic_ratio(dom["kernel"], args.precision),
                         share_of_timed_region=dom["ms"] * max(1, args.profile_period) / 1e3 / dt,
                         sampled="HIP events bracket every %d-th minibatch update (same launch sizes in all of them)" % max(1, args.profile_period))
         out = {"metric": "env steps/sec (whole node), coinrun hard-500 IMPALA-CNN PPO", "value": value, "unit": "env steps/s",
@@ -260,6 +285,11 @@ def main():
                                       f"A={A}, frames resident in HBM" + (" + per-step H2D" if args.h2d else ""),
                           "parallelism": f"dp{world} over n_envs"},
                "roofline": roof,
+               # SURVEY 8(d), whole path: env steps/s per GPU x (B_step, F_step) of the layer-boundary model against the HBM / matrix peaks
+               "whole_step_roofline": (lambda per_gpu, b_step, f_step, mpeak: {
+                   "B_step_MB": b_step / 1e6, "F_step_MFLOP": f_step / 1e6, "hbm_frac": per_gpu * b_step / (HBM_PEAK_GBS * 1e9),
+                   "mfma_frac": per_gpu * f_step / (mpeak * 1e12)})(value / world, 8.99e6 if args.precision == "bf16" else 17.90e6, 601.78e6,
+                                                                   MFMA_BF16_PEAK_TF if args.precision == "bf16" else MFMA_F32_PEAK_TF),
                "phase_ms_per_step": {"rollout": phase["rollout_s"] / args.steps * 1e3, "update": (dt - phase["rollout_s"]) / args.steps * 1e3},
                "kernel_profile_period": (0 if args.no_kernel_profile else max(1, args.profile_period)),    # kernels[]: the bracketed sample only
                "kernels": sorted(prof, key=lambda r: -r["ms"])[:24],

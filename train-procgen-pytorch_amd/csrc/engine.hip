@@ -575,7 +575,8 @@ static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const f
     a.lut = c->lut; a.n = n; a.relu_in = 0; a.bf16 = c->bf;
     a.wbank = (c->bf && L.bank_d >= 0) ? c->banks + L.bank_d : nullptr;
     const double px = (double)n * L.hw * L.hw;
-    ProfScope ps(c, PC_CONV_DGRAD + (int)L.shape, n, px * c->es * (L.cout + L.cin * (1 + (mask ? 1 : 0) + (res ? 1 : 0))), px * 18.0 * L.cin * L.cout);
+    const double pool_b = pool_arg ? c->es * (px / 4 * L.cout + 2.0 * px * L.cout) : 0.0;      // POOLIN: the max-pool backward (p + 2X of SURVEY 8(d)) rides along
+    ProfScope ps(c, PC_CONV_DGRAD + (int)L.shape, n, px * c->es * (L.cout + L.cin * (1 + (mask ? 1 : 0) + (res ? 1 : 0))) + pool_b, px * 18.0 * L.cin * L.cout);
     launch_conv_dgrad(L.shape, a, c->stream);
 }
 static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const InputSrc* src, int relu_in, const float* dout, int n, const uint8_t* pool_arg = nullptr) {
@@ -589,7 +590,9 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
     if (grid < 1) return;
     if (grid > 1024) { fprintf(stderr, "mi355ppo: wgrad slab workspace too small\n"); abort(); }
     const double px = (double)n * L.hw * L.hw;
-    { ProfScope ps(c, PC_CONV_WGRAD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : c->es * L.cin) + (pool_arg ? 0.75 : 1.0) * c->es * L.cout), px * 18.0 * L.cin * L.cout);
+    { // SURVEY 8(d) layer-boundary bytes; block1.conv from the pooled gradient also carries the max-pool backward (p + 2X)
+      const double pool_b = (pool_arg && L.cin == 3) ? c->es * (px / 4 * L.cout + 2.0 * px * L.cout) : 0.0;
+      ProfScope ps(c, PC_CONV_WGRAD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : c->es * L.cin) + c->es * L.cout) + pool_b, px * 18.0 * L.cin * L.cout);
       launch_conv_wgrad(L.shape, a, c->stream); }
     // the slabs of all layers are summed by ONE launch at the end of net_backward (conv_wgrad_reduce_all)
     const int wlen = L.cout * 9 * L.cin;
@@ -670,13 +673,13 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
                 a.in = src.base; a.idx = src.idx; a.in_base = src.first; a.w = c->params + L[0].w_off; a.bias = c->params + L[0].b_off;
                 a.n = n; a.bf16 = 1; a.lut16 = c->lut16;
                 const double px = (double)n * 64 * 64;
-                ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, px * 3.0 + px / 4 * 16 * 3.0, px * 18.0 * 3 * 16);
+                ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, px * 3.0 + 2.0 * (2.0 * px * 16 + px / 4 * 16), px * 18.0 * 3 * 16);      // conv I + X, pool X + p
                 launch_conv1_pool_fwd_bf16(a, c->lut16, k.P0, k.PI, c->stream);
             } else if (c->bf && L[0].bank_f >= 0) {       // block2.conv / block3.conv + max pool fused as well (convpool_bf16.hip)
                 ConvArgs a{};
                 a.in = prev; a.bias = c->params + L[0].b_off; a.n = n; a.bf16 = 1; a.wbank = c->banks + L[0].bank_f;
                 const double px = (double)n * L[0].hw * L[0].hw;
-                ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, px * 2.0 * L[0].cin + px / 4 * L[0].cout * 3.0, px * 18.0 * L[0].cin * L[0].cout);
+                ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, 2.0 * (px * L[0].cin + 2.0 * px * L[0].cout + px / 4 * L[0].cout), px * 18.0 * L[0].cin * L[0].cout);      // 8(d): I + 2X + p
                 if (!launch_conv_pool_fwd_bf16(L[0].shape, a, k.P0, k.PI, c->stream)) { fprintf(stderr, "mi355ppo: no fused conv+pool kernel for this shape\n"); abort(); }
             } else {
             if (b == 0) conv_fwd(c, L[0], nullptr, &src, 0, nullptr, k.C, n);
@@ -688,7 +691,7 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
                 const double px = (double)n * L[1].hw * L[1].hw, ch = L[1].cout;
                 const float* bb[4] = {c->params + L[1].b_off, c->params + L[2].b_off, c->params + L[3].b_off, c->params + L[4].b_off};
                 const unsigned short* bk[4] = {c->banks + L[1].bank_f, c->banks + L[2].bank_f, c->banks + L[3].bank_f, c->banks + L[4].bank_f};
-                ProfScope ps(c, PC_RESBLOCK + (int)L[1].shape, n, px * ch * 2.0 * (train ? 5 : 2), 4.0 * px * 18.0 * ch * ch);
+                ProfScope ps(c, PC_RESBLOCK + (int)L[1].shape, n, px * ch * 2.0 * 10, 4.0 * px * 18.0 * ch * ch);      // 8(d): 2 blocks x (2 convs x 2p + skip p) = 10p (the kernel itself moves 5p)
                 launch_resblock_pair_bf16(L[1].shape, k.P0, bb, train ? k.A1 : nullptr, train ? k.P1 : nullptr, train ? k.A2 : nullptr, k.P2, n, bk, c->stream);
             } else {
                 conv_fwd(c, L[1], k.P0, nullptr, 1, nullptr, k.A1, n);
@@ -760,7 +763,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             auto rb_full32 = [&](const ConvLayer& l1, const ConvLayer& l2, const float* dy, const float* a_fwd, const float* x_fwd, float* dx) {
                 const int grid = resblock_bwd_full32_grid(l1.shape, n);
                 const int i1 = (int)(&l1 - c->convs.data()), i2 = (int)(&l2 - c->convs.data());
-                { ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 4, 4.0 * px * 18.0 * ch * ch);
+                { ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 7, 4.0 * px * 18.0 * ch * ch);      // 8(d): 2 convs x 3p + skip-gradient p = 7p (the kernel itself moves 4p)
                   launch_resblock_bwd_full32_bf16(l1.shape, dy, a_fwd, x_fwd, dx, nullptr, n, c->banks + l2.bank_d, c->banks + l1.bank_d,
                                                   c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], c->stream); }
                 const int wlen = l1.cout * 9 * l1.cin;
@@ -783,7 +786,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
                 auto rb_full = [&](const ConvLayer& l1, const ConvLayer& l2, const float* dy, const float* a_fwd, const float* x_fwd, float* dx) {
                     const int grid = resblock_bwd_full_grid(n);
                     const int i1 = (int)(&l1 - c->convs.data()), i2 = (int)(&l2 - c->convs.data());
-                    { ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 4, 4.0 * px * 18.0 * ch * ch);
+                    { ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 7, 4.0 * px * 18.0 * ch * ch);      // 8(d): 2 convs x 3p + skip-gradient p = 7p (the kernel itself moves 4p)
                       launch_resblock_bwd_full_bf16(dy, a_fwd, x_fwd, dx, nullptr, n, c->banks + l2.bank_d, c->banks + l1.bank_d,
                                                     c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], c->stream); }
                     const int wlen = l1.cout * 9 * l1.cin;
@@ -824,7 +827,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
                 a.in = Gout; a.pool_arg = k.PI; a.out = Ga; a.n = n; a.bf16 = 1; a.wbank = c->banks + L[0].bank_d;
                 a.wg_in = c->blk[b - 1].P2; a.wg_partial = c->slabs + c->slab_off[layer];
                 const double px = (double)n * L[0].hw * L[0].hw;
-                { ProfScope ps(c, PC_CONV_DGRAD + (int)L[0].shape, n, px * 2.0 * (2 * L[0].cin + 0.75 * L[0].cout), 2.0 * px * 18.0 * L[0].cin * L[0].cout);
+                { ProfScope ps(c, PC_CONV_DGRAD + (int)L[0].shape, n, 2.0 * (px / 4 * L[0].cout + 3.0 * px * L[0].cout + 2.0 * px * L[0].cin), 2.0 * px * 18.0 * L[0].cin * L[0].cout);      // 8(d): pool bwd p + 2X, conv bwd X + 2I
                   launch_conv_dgrad(L[0].shape, a, c->stream); }
                 const int wlen = L[0].cout * 9 * L[0].cin;
                 c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[layer], (long long)L[0].w_off, (long long)L[0].b_off, fgrid, wlen + L[0].cout, wlen};
