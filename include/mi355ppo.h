@@ -96,6 +96,11 @@ int mi_rollout_step(mi_ctx* ctx, int32_t t, const float* rew_prev, const float* 
  *      (what Storage.store / store_last do with the same arrays, common/storage.py:39-54) without a second PCIe trip. */
 int mi_predict_staged(mi_ctx* ctx, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
                       int64_t* act_out, float* logp_out, float* value_out);
+/* PPO.predict_w_value_saliency (agents/ppo.py:83-94): mi_predict_staged + d value / d observation (value.backward()): grad_out is
+ * [E][64][64][3] floats (NHWC, with respect to the k/255 float frames) for IMPALA, [E][obs_dim] for the MLP.  Not for recurrent
+ * policies; discards (zeroes) the parameter-gradient buffer, so not inside an accumulating update. */
+int mi_value_saliency(mi_ctx* ctx, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
+                      int64_t* act_out, float* logp_out, float* value_out, float* grad_out);
 int mi_commit_staged(mi_ctx* ctx, int32_t t);
 
 /* ---- recurrent policies (CategoricalPolicy(recurrent=True), common/policy.py:48-50,66-67; GRU.forward prediction

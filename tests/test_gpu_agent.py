@@ -76,6 +76,14 @@ def test_public_predict_store_path_equals_fast_path():
     assert set(summary) == {'Loss/pi', 'Loss/v', 'Loss/entropy', 'Loss/x_entropy', 'Loss/atn_entropy', 'Loss/atn_entropy2',
                             'Loss/sparsity', 'Loss/feature_sparsity', 'Loss/total'}
     assert np.isfinite(summary['Loss/total']) and np.isnan(summary['Loss/sparsity'])
+    # predict_w_value_saliency (agents/ppo.py:83-94; render.py --value_saliency): same prediction + the input gradient of the value, in
+    # the observation's own layout; uint8 frames and the reference's scaled floats are the same observation
+    a_s, lp_s, v_s, h_s, sal = agent.predict_w_value_saliency(ref_obs, hidden, done)
+    assert sal.shape == ref_obs.shape and np.isfinite(sal).all() and np.abs(sal).max() > 0
+    _, _, v_p, _ = agent.predict(seen[1][0], hidden, done)
+    np.testing.assert_allclose(v_s, v_p, atol=1e-6)
+    _, _, _, sal_u8 = agent.engine.value_saliency(seen[1][0], seed=0)
+    np.testing.assert_array_equal(sal, sal_u8.transpose(0, 3, 1, 2))
 
 
 def test_checkpoint_roundtrip_in_reference_format(tmp_path):

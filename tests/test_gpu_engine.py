@@ -370,3 +370,45 @@ def test_error_paths():
         eng.put_obs(9, np.zeros((4, 9), np.float32))
     eng.minibatch(np.zeros(0, np.int64), 4, eng.hparams())  # empty local shard of a global minibatch
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ value saliency
+@pytest.mark.parametrize("arch,precision", [("impala", "fp32"), ("impala", "bf16"), ("mlp", "fp32")])
+def test_value_saliency_matches_autograd(arch, precision):
+    """PPO.predict_w_value_saliency (agents/ppo.py:83-94): d value / d observation from the engine's own backward pass
+    (training-mode forward, dY = e_value, down to the network input) against torch autograd through the CPU oracle.
+    fp32: 2e-3 of the gradient's scale (ReLU / max-pool decisions that flip with summation order move single pixels);
+    bf16 storage: direction only (cos > 0.9).  The pass must leave the parameter-gradient buffer zeroed."""
+    from mi355 import layout
+    from mi355.engine import Engine
+    E, A = 4, (15 if arch == "impala" else 2)
+    params = golden_params(arch)
+    shapes = shapes_for(arch, A)
+    rng = np.random.default_rng(11)
+    if arch == "impala":
+        eng = Engine("impala", 2, E, A, E, precision=precision)
+        obs_dev = rng.integers(0, 256, size=(E, 64, 64, 3), dtype=np.uint8)
+        x = O.frames_to_obs(obs_dev).clone().requires_grad_(True)
+    else:
+        eng = Engine("mlp", 2, E, A, E, obs_dim=9, mlp_depth=4, mlp_width=256, out_dim=64)
+        obs_dev = rng.standard_normal((E, 9)).astype(np.float32)
+        x = torch.from_numpy(obs_dev).clone().requires_grad_(True)
+    eng.set_params(layout.flatten(shapes, params))
+    p = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()}
+    lp, v, _ = O.policy_forward(p, arch, x)
+    v.sum().backward()
+    ref = x.grad.numpy()
+    act, logp, val, grad = eng.value_saliency(obs_dev, seed=3)
+    if arch == "impala":
+        grad = grad.transpose(0, 3, 1, 2)
+    assert np.abs(ref).max() > 0
+    if precision == "fp32":
+        np.testing.assert_allclose(val, v.detach().numpy(), rtol=0, atol=2e-5)
+        assert np.abs(grad - ref).max() < 2e-3 * np.abs(ref).max()
+    else:
+        cos = float((grad * ref).sum() / (np.linalg.norm(grad) * np.linalg.norm(ref) + 1e-30))
+        assert cos > 0.9, cos
+    assert not np.any(eng.get_grads())                      # the pass's parameter gradients were discarded
+    a2, l2, v2 = eng.predict_staged(obs_dev, seed=3)        # same staged prediction as the plain entry point
+    assert np.array_equal(a2, act) and np.allclose(l2, logp, atol=1e-6) and np.allclose(v2, val, atol=1e-6)
+    eng.close()

@@ -125,7 +125,19 @@ class PPO(BaseAgent):
         return act, logp, value, (self.engine.get_hidden() if rec else np.asarray(hidden_state))
 
     def predict_w_value_saliency(self, obs, hidden_state, done):
-        raise NotImplementedError("value saliency (input gradient) is a 'next' row of SURVEY 8(f), not built yet")
+        """agents/ppo.py:83-94: predict + the gradient of the value with respect to the observation, in the observation's
+        layout ((E,3,64,64) for frames).  Each env's value depends on its own observation only, so this is the gradient of
+        sum_e value_e (the reference's value.backward() needs n_envs = 1, as render.py uses it)."""
+        if self.policy.is_recurrent():
+            raise NotImplementedError("value saliency through the GRU is not built")
+        self._predict_calls = getattr(self, "_predict_calls", 0) + 1
+        act, logp, value, grad = self.engine.value_saliency(as_device_obs(obs, self.policy.arch),
+                                                            seed=self.seed * 1000003 + self._iter,
+                                                            counter=self._predict_calls * self.n_envs)
+        self.storage.note_predicted(-1, obs, act, logp, value)
+        if self.policy.arch == "impala":
+            grad = np.ascontiguousarray(grad.transpose(0, 3, 1, 2))          # NHWC -> the reference's (E,3,64,64)
+        return act, logp, value, np.asarray(hidden_state), grad
 
     # ------------------------------------------------------------------ optimize
     def _hparams(self):

@@ -145,6 +145,8 @@ void launch_adam(float* p, float* g, float* m, float* v, long long n, const doub
                  float beta1, float beta2, float eps, float step_size_scale, float bc2_sqrt, float* gnorm_out,
                  hipStream_t st);
 void launch_fill(float* p, long long n, float v, hipStream_t st);
+void launch_value_seed(float* dY, int n, int A, hipStream_t st);
+void launch_conv1_input_grad(const void* dC, int bf16, const float* W, float* dX, int n, hipStream_t st);
 void launch_mask_rows(const float* h, const float* done, float* out, int n, int H, hipStream_t st);   // out = h * (1 - done[row])
 void launch_gru_gates(const float* gi, const float* gh, const float* hm, float* h_out, float* feat_out, int n, int H, hipStream_t st);
 

@@ -93,6 +93,7 @@ struct mi_ctx {
     int64_t wh_off, bh_off;        // heads: (A+1) x H weights, (A+1) bias (device order)
     float *feat, *hout, *dY, *dfeat, *GC, *GP[3];
     float* slabs; size_t slab_floats;
+    void* sal_dc; float* sal_dx; const float* sal_src;       // value saliency: conv-out gradient temp (bf16 mode), input gradient, where net_backward left block 1's gradient
     long long slab_off[15]; SlabDesc h_slab_desc[15]; SlabDesc* d_slab_desc; int slab_desc_n, slab_desc_cached_n;   // per-layer slab regions; ONE reduce launch per backward pass
     float *gemm_ws, *col_ws, *fs_scratch, *fs_val;
     float* lut;
@@ -337,7 +338,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->h_f_floats = (size_t)4 * (E > 64 ? E : 64);
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
-    c->multirank = 0; c->pending_n = -1;
+    c->multirank = 0; c->pending_n = -1; c->sal_dc = nullptr; c->sal_dx = nullptr; c->sal_src = nullptr;
     c->fc_wp = c->fc_wt = nullptr; c->fc_packed_valid = false;
     if (c->bf) { HIPC(dalloc(&c->fc_wp, (size_t)256 * 2048)); HIPC(dalloc(&c->fc_wt, (size_t)256 * 2048)); }
     c->banks = nullptr; c->d_bank_desc = nullptr; c->n_banks = 0;
@@ -381,7 +382,7 @@ int mi_destroy(mi_ctx* c) {
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
     if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc);
-    if (c->d_slab_desc) hipFree(c->d_slab_desc); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
+    if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
@@ -729,7 +730,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         const float* dy = c->dfeat;
         for (size_t l = L; l-- > 0;) {
             linear_wgrad(c, dy, c->mlp_act[l], 0, c->grads + c->mlp[l].w_off, c->grads + c->mlp[l].b_off, n, c->mlp[l].in, c->mlp[l].out);
-            if (l == 0) break;
+            if (l == 0) { c->sal_src = dy; break; }
             float* dx = c->GP[l & 1];
             linear_dgrad(c, dy, c->params + c->mlp[l].w_off, c->mlp_act[l], dx, n, c->mlp[l].in, c->mlp[l].out);
             dy = dx;
@@ -818,7 +819,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         conv_dgrad(c, L[1], Ga, k.P0, Gb, Gout, n);
         }
         // max pool, then the block's first conv
-        if (b == 0 && c->bf) { conv_wgrad(c, L[0], nullptr, &src, 0, Gout, n, k.PI); break; }     // pool backward fused into the staging
+        if (b == 0 && c->bf) { c->sal_src = Gout; conv_wgrad(c, L[0], nullptr, &src, 0, Gout, n, k.PI); break; }     // pool backward fused into the staging
         if (c->bf) {            // blocks 2, 3: both consumers of the conv-output gradient rebuild it from (pooled gradient, arg-max)
             const int fgrid = conv_bwd_fused_grid(L[0].shape, n);
             if (fgrid > 0) {        // block2.conv: data AND weight gradient in one launch (the max-pool backward gather runs once)
@@ -840,7 +841,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         }
         { ProfScope ps(c, PC_POOL_BWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
           if (c->bf) launch_maxpool_bwd_bf16(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); else launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); }
-        if (b == 0) conv_wgrad(c, L[0], nullptr, &src, 0, c->GC, n);
+        if (b == 0) { c->sal_src = c->GC; conv_wgrad(c, L[0], nullptr, &src, 0, c->GC, n); }
         else {
             conv_wgrad(c, L[0], c->blk[b - 1].P2, nullptr, 0, c->GC, n);
             conv_dgrad(c, L[0], c->GC, nullptr, nullptr, Gout, n);
@@ -921,6 +922,57 @@ int mi_predict_staged(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, u
     HIPC(hipMemcpyAsync(c->h_i, c->s_act, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipMemcpyAsync(c->h_f, c->s_logp, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipMemcpyAsync(c->h_f + E, c->s_val, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    c->staged_valid = true;
+    if (act_out) for (int e = 0; e < E; ++e) act_out[e] = c->h_i[e];
+    if (logp_out) memcpy(logp_out, c->h_f, (size_t)E * 4);
+    if (value_out) memcpy(value_out, c->h_f + E, (size_t)E * 4);
+    return 0;
+}
+
+// PPO.predict_w_value_saliency (agents/ppo.py:83-94): predict + d value / d observation.  grad_out: IMPALA [E][64][64][3] (NHWC,
+// wrt the k/255 float frames), MLP [E][obs_dim].  Runs the training-mode forward and the whole backward pass with dY = e_value on
+// the E staged observations; the parameter gradients it produces on the way are discarded (the gradient buffer is zeroed again),
+// so it must not be called between mi_minibatch and mi_optimizer_step of an accumulating update.
+int mi_value_saliency(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
+                      int64_t* act_out, float* logp_out, float* value_out, float* grad_out) {
+    ARG(c && obs && grad_out, "null");
+    ARG(!c->gru_on, "value saliency through the GRU is not built");
+    ARG(c->pending_n < 0, "a multirank minibatch is pending");
+    const int E = c->E;
+    const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
+    ARG(bytes == (size_t)E * c->obs_bytes_per_env, "obs byte count != E * bytes_per_env");
+    void* stage = c->stage_frames ? (void*)c->stage_frames : (void*)c->stage_obs;
+    HIPC(hipMemcpyAsync(stage, obs, bytes, hipMemcpyHostToDevice, c->stream));
+    const float* du = nullptr;
+    if (u) { HIPC(hipMemcpyAsync(c->d_u, u, (size_t)E * 4, hipMemcpyHostToDevice, c->stream)); du = c->d_u; }
+    InputSrc src{stage, nullptr, 0};
+    c->prof.phase = 0;
+    net_forward(c, src, E, false, true, true);
+    launch_sample(c->hout, E, c->A, du, seed, counter, c->s_act, c->s_logp, c->s_val, c->stream);
+    launch_value_seed(c->dY, E, c->A, c->stream);
+    c->sal_src = nullptr;
+    net_backward(c, src, E);
+    ARG(c->sal_src, "backward did not reach the first layer");
+    const size_t gfloats = impala ? (size_t)E * 64 * 64 * 3 : (size_t)E * c->cfg.obs_dim;
+    if (!c->sal_dx) HIPC(dalloc(&c->sal_dx, impala ? (size_t)c->NB * 64 * 64 * 3 : (size_t)c->NB * c->cfg.obs_dim));
+    if (impala) {
+        const void* dC = c->sal_src;
+        if (c->bf) {                                       // the conv-output gradient is not materialised in bf16 mode: rebuild it from the pooled one
+            if (!c->sal_dc) HIPC(hipMalloc(&c->sal_dc, (size_t)c->NB * 64 * 64 * 16 * 2 + 256));
+            launch_maxpool_bwd_bf16(c->sal_src, c->blk[0].PI, c->sal_dc, E, 64, 16, c->stream);
+            dC = c->sal_dc;
+        }
+        launch_conv1_input_grad(dC, c->bf, c->params + c->convs[0].w_off, c->sal_dx, E, c->stream);
+    } else {
+        linear_dgrad(c, c->sal_src, c->params + c->mlp[0].w_off, nullptr, c->sal_dx, E, c->mlp[0].in, c->mlp[0].out);
+    }
+    launch_fill(c->grads, c->n_params, 0.f, c->stream);    // discard the parameter gradients of this pass
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(c->h_i, c->s_act, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(c->h_f, c->s_logp, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(c->h_f + E, c->s_val, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(grad_out, c->sal_dx, gfloats * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     c->staged_valid = true;
     if (act_out) for (int e = 0; e < E; ++e) act_out[e] = c->h_i[e];

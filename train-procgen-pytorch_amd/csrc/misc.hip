@@ -929,3 +929,48 @@ void launch_gru_gates(const float* gi, const float* gh, const float* hm, float* 
     if (n <= 0) return;
     hipLaunchKernelGGL(gru_gates_kernel, dim3((n * H + 255) / 256), dim3(256), 0, st, gi, gh, hm, h_out, feat_out, n, H);
 }
+
+// ------------------------------------------------------------------------------------------ value saliency (agents/ppo.py:83-94)
+// value.backward() seeds dY = e_value for every env; the backward pass then runs down to the network input.  The last step,
+// the input gradient of block1.conv (16 -> 3 channels @64x64), exists for this path only: one thread per pixel, direct form.
+__global__ void value_seed_kernel(float* dY, int n, int A) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * (A + 1)) return;
+    dY[e] = (e % (A + 1) == A) ? 1.f : 0.f;
+}
+void launch_value_seed(float* dY, int n, int A, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(value_seed_kernel, dim3((n * (A + 1) + 255) / 256), dim3(256), 0, st, dY, n, A);
+}
+template <bool BF>
+__global__ __launch_bounds__(256) void conv1_input_grad_kernel(const void* dC, const float* __restrict__ W, float* __restrict__ dX, int n) {
+    __shared__ float sw[16 * 9 * 3];                       // device layout [co][tap][ci]
+    for (int k = threadIdx.x; k < 432; k += 256) sw[k] = W[k];
+    __syncthreads();
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long long)n * 4096) return;
+    const int x = (int)(p & 63), y = (int)((p >> 6) & 63);
+    const long long img = p >> 12;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + 1 - ky;                          // forward: out[yy][xx] read in[yy - 1 + ky][xx - 1 + kx]
+        if (yy < 0 || yy >= 64) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x + 1 - kx;
+            if (xx < 0 || xx >= 64) continue;
+            const long long o = ((img * 64 + yy) * 64 + xx) * 16;
+            for (int co = 0; co < 16; ++co) {
+                const float g = BF ? __uint_as_float(((unsigned)((const unsigned short*)dC)[o + co]) << 16) : ((const float*)dC)[o + co];
+                const float* w = sw + (co * 9 + ky * 3 + kx) * 3;
+                acc[0] += g * w[0]; acc[1] += g * w[1]; acc[2] += g * w[2];
+            }
+        }
+    }
+    dX[p * 3] = acc[0]; dX[p * 3 + 1] = acc[1]; dX[p * 3 + 2] = acc[2];
+}
+void launch_conv1_input_grad(const void* dC, int bf16, const float* W, float* dX, int n, hipStream_t st) {
+    if (n <= 0) return;
+    const unsigned grid = (unsigned)(((long long)n * 4096 + 255) / 256);
+    if (bf16) hipLaunchKernelGGL(conv1_input_grad_kernel<true>, dim3(grid), dim3(256), 0, st, dC, W, dX, n);
+    else hipLaunchKernelGGL(conv1_input_grad_kernel<false>, dim3(grid), dim3(256), 0, st, dC, W, dX, n);
+}

@@ -39,7 +39,7 @@ def lib_path():
 
 EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_param_count mi_set_params "
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
-           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_predict_staged mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
+           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_optimizer_step mi_loss_log_read mi_device_ptr "
            "mi_set_multirank mi_minibatch_finish mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
 
@@ -220,6 +220,17 @@ class Engine:
         self._chk(self.lib.mi_predict_staged(self._ctx, _fp(obs), C.c_size_t(obs.nbytes), C.c_uint64(seed),
                                              C.c_uint64(counter), _fp(u), _fp(act), _fp(logp), _fp(val)))
         return act, logp, val
+
+    def value_saliency(self, obs, seed=0, counter=0, u=None):
+        """predict_staged + d value / d observation: (act, logp, value, grad) with grad (E,64,64,3) NHWC for IMPALA / (E,obs_dim) for the MLP."""
+        want = np.uint8 if self.arch == ARCH_IMPALA else np.float32
+        obs = np.ascontiguousarray(obs, dtype=want)
+        u = None if u is None else _f32(u)
+        act, logp, val = np.empty(self.E, np.int64), np.empty(self.E, np.float32), np.empty(self.E, np.float32)
+        grad = np.empty((self.E, 64, 64, 3) if self.arch == ARCH_IMPALA else (self.E, self.obs_dim), np.float32)
+        self._chk(self.lib.mi_value_saliency(self._ctx, _fp(obs), C.c_size_t(obs.nbytes), C.c_uint64(seed), C.c_uint64(counter), _fp(u),
+                                             _fp(act), _fp(logp), _fp(val), _fp(grad)))
+        return act, logp, val, grad
 
     def commit_staged(self, t):
         self._chk(self.lib.mi_commit_staged(self._ctx, C.c_int32(t)))
