@@ -137,11 +137,15 @@ int mi_optimizer_step(mi_ctx* ctx, float lr, float max_grad_norm, int32_t adam_s
 int mi_loss_log_read(mi_ctx* ctx, float* out, int32_t max_records, int32_t* n_records, int32_t reset);
 
 /* ---- raw device pointers for collectives issued by the host side (RCCL through torch.distributed) */
-enum { MI_PTR_GRADS = 0, MI_PTR_LOSS_STATS = 1, MI_PTR_PARAMS = 2 };
+enum { MI_PTR_GRADS = 0, MI_PTR_LOSS_STATS = 1, MI_PTR_PARAMS = 2, MI_PTR_STATS_RING = 3 };
 int mi_device_ptr(mi_ctx* ctx, int32_t which, void** ptr, int64_t* n_floats);
 /* two-phase loss finalisation for multi-rank runs (phase 2 after the cross-rank sum of the stats) */
-int mi_set_multirank(mi_ctx* ctx, int32_t enabled);
-int mi_minibatch_finish(mi_ctx* ctx);      /* multirank only: phase 2 + backward after the stats all-reduce */
+int mi_set_multirank(mi_ctx* ctx, int32_t enabled);   /* 0 single rank; 1 stats all-reduced per minibatch (mi_minibatch_finish); 2 deferred */
+int mi_minibatch_finish(mi_ctx* ctx);      /* multirank mode 1: phase 2 + backward after the stats all-reduce */
+/* multirank mode 2 (x_entropy_coef == 0 and fs_coef == 0: the backward pass needs no cross-rank statistic): mi_minibatch runs to
+ * completion, this rank's partial loss sums of minibatch k go to ring slot k (MI_PTR_STATS_RING, 32 floats each); once per
+ * optimize() the caller sums the first 32 * n_minibatches floats over the ranks and calls mi_loss_log_finalize. */
+int mi_loss_log_finalize(mi_ctx* ctx);
 
 /* ---- live kernel timing for bench.py's roofline leg: HIP events recorded on the context's stream around every
  *      conv / pool / GEMM launch.  Classes are reported separately for the rollout phase (phase 0, n = E) and the

@@ -183,6 +183,7 @@ import os, sys, numpy as np, torch, torch.distributed as dist
 rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
 sys.path[:0] = [sys.argv[5], sys.argv[6]]
 precision = sys.argv[7] if len(sys.argv) > 7 else "fp32"
+xcoef = float(sys.argv[8]) if len(sys.argv) > 8 else 0.02
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -198,7 +199,7 @@ policy = CategoricalPolicy(ImpalaModel(3), False, A)
 storage = Storage((3, 64, 64), 256, T, E, torch.device("cuda", 0))
 class L: episode_reward_buffer = [0.0]; logdir = "/tmp"
 agent = PPO(None, policy, L(), storage, torch.device("cuda", 0), 1, n_steps=T, n_envs=E, epoch=1, n_minibatch=1,
-            mini_batch_size=16, gamma=0.999, lmbda=0.95, learning_rate=5e-4, x_entropy_coef=0.02, precision=precision)
+            mini_batch_size=16, gamma=0.999, lmbda=0.95, learning_rate=5e-4, x_entropy_coef=xcoef, precision=precision)
 rng = np.random.default_rng(0)
 frames = rng.integers(0, 256, size=(T + 1, EG, 64, 64, 3), dtype=np.uint8)
 act = rng.integers(0, A, (T, EG)); logp = (np.log(1 / A) + 0.2 * rng.standard_normal((T, EG))).astype(np.float32)
@@ -221,22 +222,24 @@ if world > 1:
 '''
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path, precision):
+@pytest.mark.parametrize("precision,xcoef", [("fp32", 0.02), ("bf16", 0.02), ("fp32", 0.0), ("bf16", 0.0)])
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path, precision, xcoef):
     """The real multi-rank engine path (mi_set_multirank, loss-stats + gradient all-reduce on aliased device
     buffers, merged advantage statistics) with 2 processes sharing the GPU over `gloo`, against the 1-process run
     on the same global rollout and the same permutation stream: one optimizer step fed by two accumulated
     global minibatches of 16 (N = 32).  (Longer trajectories are chaotic: a 3e-8 parameter difference after step 1
     flips single ReLU / max-pool decisions in step 2 and Adam amplifies it -- measured 5e-4 after 4 steps at B = 8.)
     bf16: every sample's activations are the same whichever rank computes them (the fused kernels work per image); only the fp32
-    summation order of the weight gradients differs, as in fp32."""
+    summation order of the weight gradients differs, as in fp32.
+    xcoef = 0.02 takes multirank mode 1 (loss statistics all-reduced per minibatch, the x-entropy gradient needs them); xcoef = 0
+    takes mode 2 (statistics ring reduced once per optimize(), mi_loss_log_finalize)."""
     script = tmp_path / "two_rank.py"
     script.write_text(_TWO_RANK)
     port = str(29600 + os.getpid() % 1000)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = str(tmp_path / "one.npz"); two = str(tmp_path / "two.npz")
-    subprocess.run([sys.executable, str(script), "0", "1", port, one, ROOT, PKG, precision], check=True, env=env, timeout=300)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, two, ROOT, PKG, precision], env=env) for r in range(2)]
+    subprocess.run([sys.executable, str(script), "0", "1", port, one, ROOT, PKG, precision, str(xcoef)], check=True, env=env, timeout=300)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, two, ROOT, PKG, precision, str(xcoef)], env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     a, b = np.load(one), np.load(two)

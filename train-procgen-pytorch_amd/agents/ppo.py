@@ -14,7 +14,7 @@ import torch
 from common.misc_util import adjust_lr, adjust_lr_grok
 from common.model import as_device_obs
 from mi355.dist import Collective, DevicePointerTensor, shard_indices
-from mi355.engine import Engine, PTR_GRADS, PTR_LOSS_STATS
+from mi355.engine import Engine, PTR_GRADS, PTR_LOSS_STATS, PTR_STATS_RING
 from mi355.optim import DeviceAdam
 from .base_agent import BaseAgent
 
@@ -77,13 +77,15 @@ class PPO(BaseAgent):
                 g = policy.gru.gru
                 self.engine_valid.set_gru(*(t.detach().numpy() for t in (g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)))
         self.optimizer = DeviceAdam(policy, self.engine, learning_rate, eps=1e-5)
-        self._grads_t = self._stats_t = None
+        self._grads_t = self._stats_t = self._ring_t = None
         if self.coll.active:
             self.engine.set_multirank(True)
             gp, gn = self.engine.device_ptr(PTR_GRADS)
             sp, sn = self.engine.device_ptr(PTR_LOSS_STATS)
             self._grads_t = DevicePointerTensor(gp, gn).tensor(dev_index)
             self._stats_t = DevicePointerTensor(sp, sn).tensor(dev_index)
+            rp, rn = self.engine.device_ptr(PTR_STATS_RING)
+            self._ring_t = DevicePointerTensor(rp, rn).tensor(dev_index)
         self._stage = [self.engine.pinned((n_envs,) + self._obs_stage_shape(arch, emb), self._obs_dtype(arch)) for _ in range(2)]
         self._stage_i = 0
         self._iter = 0
@@ -159,11 +161,19 @@ class PPO(BaseAgent):
         cnt = 1
         eng, coll, hp = self.engine, self.coll, self._hparams()
         recurrent = self.policy.is_recurrent()
+        # Multi-rank: the backward pass needs a cross-rank statistic (the batch-mean action distribution) only for the x-entropy
+        # term; without it (and without the feature-sparsity term) every rank runs its minibatches straight through and the
+        # logged loss sums are reduced over the ranks ONCE per optimize() instead of once per minibatch.
+        deferred = coll.active and self.x_entropy_coef == 0 and self.fs_coef == 0
+        n_mb = 0
+        if coll.active:
+            eng.set_multirank(2 if deferred else 1)
         for _ in range(self.epoch):
             for chunk in self.storage.minibatch_index_stream(self.mini_batch_size, recurrent, self.n_envs_global):
                 local = shard_indices(chunk, self.n_envs_global, coll.rank, coll.world)
                 eng.minibatch(local, len(chunk), hp)
-                if coll.active:
+                n_mb += 1
+                if coll.active and not deferred:
                     with torch.cuda.stream(self._tstream):
                         coll.allreduce_sum_(self._stats_t)   # 32 floats: loss sums + mean action probabilities
                     eng.minibatch_finish()
@@ -173,6 +183,10 @@ class PPO(BaseAgent):
                             coll.allreduce_sum_(self._grads_t)   # ONE collective per optimizer step: the flat gradient
                     self.optimizer.step(self.grad_clip_norm)
                 cnt += 1
+        if deferred:
+            with torch.cuda.stream(self._tstream):
+                coll.allreduce_sum_(self._ring_t[:32 * n_mb])
+            eng.loss_log_finalize()
         log = eng.loss_log(reset=True)
         nan = float("nan")
         fs = float(np.mean(log[:, 5])) if self.policy.arch == "impala" else nan

@@ -101,6 +101,7 @@ struct mi_ctx {
     uint8_t* stage_frames; float* stage_obs;
     int32_t* d_idx;
     float *loss_partial, *loss_stats, *loss_log; int log_count, log_cap;
+    float *stats_ring, *fs_ring; LossArgs ring_args;      // multirank mode 2: per-minibatch raw stats [log_cap][32] (+ rank-local fs), finalised after ONE all-reduce
     double* sumsq; float* gnorm;
     float* d_u; float* d_lp;
     unsigned short* banks; BankDesc* d_bank_desc; int n_banks;   // bf16 mode: pre-packed conv filter banks
@@ -324,6 +325,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(dalloc(&c->loss_stats, 64));
     c->log_cap = 4096; c->log_count = 0;
     HIPC(dalloc(&c->loss_log, (size_t)c->log_cap * 8));
+    HIPC(dalloc(&c->stats_ring, (size_t)c->log_cap * 32)); HIPC(dalloc(&c->fs_ring, (size_t)c->log_cap));
     HIPC(dalloc(&c->sumsq, 2 + 128)); HIPC(dalloc(&c->gnorm, 2)); sumsq_set_workspace(c->sumsq + 2);
     HIPC(dalloc(&c->d_u, (size_t)E));
     HIPC(dalloc(&c->d_pack, (size_t)3 * E)); HIPC(dalloc(&c->d_rd, (size_t)2 * E));
@@ -382,7 +384,7 @@ int mi_destroy(mi_ctx* c) {
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
     if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc);
-    if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
+    hipFree(c->stats_ring); hipFree(c->fs_ring); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
@@ -1113,6 +1115,20 @@ int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, con
     a.hp = LossHP{hp->eps_clip, hp->value_coef, hp->entropy_coef, hp->x_entropy_coef, hp->entropy_multiplier, hp->fs_coef};
     launch_loss_fwd(a, c->stream);
     float* slot = c->loss_log + (size_t)c->log_count * 8;
+    if (c->multirank == 2) {
+        // deferred statistics: nothing in the backward pass needs the cross-rank sums when x_entropy_coef == 0 and fs_coef == 0, so this
+        // rank's partial sums go to ring slot log_count and are summed over the ranks ONCE per optimize() (mi_loss_log_finalize)
+        ARG(hp->x_entropy_coef == 0.f && hp->fs_coef == 0.f, "multirank mode 2 needs x_entropy_coef == 0 and fs_coef == 0 (use mode 1)");
+        LossArgs r = a; r.stats = c->stats_ring + (size_t)c->log_count * 32;
+        launch_loss_finalize(r, loss_blocks(n), 1, nullptr, nullptr, c->stream);
+        if (impala) HIPC(hipMemcpyAsync(c->fs_ring + c->log_count, c->fs_val, 4, hipMemcpyDeviceToDevice, c->stream));
+        c->ring_args = a;
+        c->log_count++;
+        launch_loss_bwd(a, c->stream);
+        net_backward(c, src, n);
+        HIPC(hipGetLastError());
+        return 0;
+    }
     if (c->multirank) {
         launch_loss_finalize(a, loss_blocks(n), 1, nullptr, nullptr, c->stream);
         c->pending = a; c->pending_n = n;
@@ -1127,7 +1143,19 @@ int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, con
     return 0;
 }
 
-int mi_set_multirank(mi_ctx* c, int32_t enabled) { ARG(c, "null"); c->multirank = enabled ? 1 : 0; return 0; }
+int mi_set_multirank(mi_ctx* c, int32_t enabled) { ARG(c, "null"); ARG(enabled >= 0 && enabled <= 2, "mode"); c->multirank = enabled; return 0; }
+
+// multirank mode 2: after the caller summed stats_ring[0 .. log_count*32) over the ranks, derive every minibatch's log record
+int mi_loss_log_finalize(mi_ctx* c) {
+    ARG(c, "null"); ARG(c->multirank == 2, "only in multirank mode 2");
+    const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
+    for (int k = 0; k < c->log_count; ++k) {
+        LossArgs r = c->ring_args; r.stats = c->stats_ring + (size_t)k * 32;
+        launch_loss_finalize(r, 0, 2, impala ? c->fs_ring + k : nullptr, c->loss_log + (size_t)k * 8, c->stream);
+    }
+    HIPC(hipGetLastError());
+    return 0;
+}
 
 int mi_minibatch_finish(mi_ctx* c) {
     ARG(c, "null"); ARG(c->pending_n >= 0, "no pending minibatch");
@@ -1179,6 +1207,7 @@ int mi_device_ptr(mi_ctx* c, int32_t which, void** ptr, int64_t* n) {
         case MI_PTR_GRADS: *ptr = c->grads; *n = c->n_params; return 0;
         case MI_PTR_LOSS_STATS: *ptr = c->loss_stats; *n = 32; return 0;
         case MI_PTR_PARAMS: *ptr = c->params; *n = c->n_params; return 0;
+        case MI_PTR_STATS_RING: *ptr = c->stats_ring; *n = (int64_t)c->log_cap * 32; return 0;
         default: return fail(-1, "unknown pointer id");
     }
 }

@@ -13,7 +13,7 @@ _LIB = None
 
 ARCH_IMPALA, ARCH_MLP = 0, 1
 F_REW, F_DONE, F_VALUE, F_LOGP, F_ADV, F_RET, F_ACT = range(7)
-PTR_GRADS, PTR_LOSS_STATS, PTR_PARAMS = 0, 1, 2
+PTR_GRADS, PTR_LOSS_STATS, PTR_PARAMS, PTR_STATS_RING = 0, 1, 2, 3
 LOSS_FIELDS = ("pi_loss", "value_loss", "entropy", "x_ent", "total", "fs", "marg", "_pad")
 
 
@@ -41,7 +41,7 @@ EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_fre
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
            "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_optimizer_step mi_loss_log_read mi_device_ptr "
-           "mi_set_multirank mi_minibatch_finish mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
+           "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
 
 
 def load_library():
@@ -291,6 +291,9 @@ class Engine:
 
     def minibatch_finish(self):
         self._chk(self.lib.mi_minibatch_finish(self._ctx))
+
+    def loss_log_finalize(self):
+        self._chk(self.lib.mi_loss_log_finalize(self._ctx))
 
     def set_multirank(self, enabled):
         self._chk(self.lib.mi_set_multirank(self._ctx, C.c_int32(int(enabled))))
