@@ -19,6 +19,50 @@ typedef __bf16 mi_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned mi_pk_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((mi_f32x2){lo, hi}, mi_bf16x2));
 }
+
+// ---- MaxPool2d(3,2,1) on order-preserving integer keys (the fused conv+pool kernels are VALU-issue bound, and a float
+// compare + two selects per (window position, channel) was most of their instruction count).
+// key16(v): signed-int16 order == float order of the bf16 value, -0 and +0 share a key.  The conv epilogue stores keys, the
+// pooling widens a key to the high half of a dword and puts (8 - window position) in the low bits: ONE v_max3_i32 per
+// three positions then yields the maximum AND its first row-major position (ties: larger low bits = earlier position --
+// the `v > best` rule of torch's max_pool2d and of the stand-alone kernel in misc.hip).  A positive NaN sorts above +inf
+// and so propagates; cells outside the image hold MI_KEY_MIN.
+typedef short mi_s16x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned MI_KEY_MIN2 = 0x80008000u;                 // two minimal keys
+__device__ __forceinline__ unsigned mi_bf16x2_to_keys(unsigned w) {
+    const mi_s16x2 v = __builtin_bit_cast(mi_s16x2, w), s = v >> (mi_s16x2){15, 15};          // 0 / -1 per half
+    return __builtin_bit_cast(unsigned, (mi_s16x2)((v ^ (s & (mi_s16x2){0x7fff, 0x7fff})) - s));
+}
+__device__ __forceinline__ unsigned mi_keys_to_bf16x2(unsigned kk) {
+    mi_s16x2 k = __builtin_bit_cast(mi_s16x2, kk);
+    const mi_s16x2 s = k >> (mi_s16x2){15, 15};
+    k = k + s;
+    return __builtin_bit_cast(unsigned, (mi_s16x2)(k ^ (s & (mi_s16x2){0x7fff, 0x7fff})));
+}
+__device__ __forceinline__ int mi_max3i(int a, int b, int c) { return max(max(a, b), c); }
+// u[p] = the 8 channel keys (4 dwords) of window position p = ky*3 + kx; val = 8 pooled bf16, arg = 8 position bytes
+__device__ __forceinline__ void mi_pool9_keys(const uint4 (&u)[9], uint4& val, uint2& arg) {
+    int best[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int k[9];
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const unsigned w = (q >> 1) == 0 ? u[p].x : (q >> 1) == 1 ? u[p].y : (q >> 1) == 2 ? u[p].z : u[p].w;
+            k[p] = (int)((q & 1) ? ((w & 0xffff0000u) | (unsigned)(8 - p)) : ((w << 16) | (unsigned)(8 - p)));
+        }
+        best[q] = mi_max3i(mi_max3i(k[0], k[1], k[2]), mi_max3i(k[3], k[4], k[5]), mi_max3i(k[6], k[7], k[8]));
+    }
+    unsigned kv[4], lo[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kv[j] = ((unsigned)best[2 * j] >> 16) | ((unsigned)best[2 * j + 1] & 0xffff0000u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)        // low bytes of four keys = 8 - position
+        lo[j] = __builtin_amdgcn_perm(__builtin_amdgcn_perm((unsigned)best[4 * j + 3], (unsigned)best[4 * j + 2], 0x0c0c0400u),
+                                      __builtin_amdgcn_perm((unsigned)best[4 * j + 1], (unsigned)best[4 * j], 0x0c0c0400u), 0x05040100u);
+    val = (uint4){mi_keys_to_bf16x2(kv[0]), mi_keys_to_bf16x2(kv[1]), mi_keys_to_bf16x2(kv[2]), mi_keys_to_bf16x2(kv[3])};
+    arg = (uint2){0x08080808u - lo[0], 0x08080808u - lo[1]};
+}
 #endif
 
 struct ConvArgs {

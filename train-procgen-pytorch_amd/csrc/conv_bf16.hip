@@ -899,7 +899,9 @@ using C1P = C1T<9>;
 __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, const unsigned short* lut16, unsigned short* p_out, uint8_t* p_arg) {
     __shared__ __attribute__((aligned(16))) unsigned short s_in[C1P::NPIX * 4];
     __shared__ __attribute__((aligned(16))) unsigned short s_w[16 * C1_WS];
-    __shared__ __attribute__((aligned(16))) unsigned short s_c[9 * 64 * 16];       // (a 1.5-pixel stride makes the pooling reads conflict-free but measured slower: 11.3 vs 8.5 ms)
+    // conv-output tile as ORDER-PRESERVING KEYS (common.h), [9 rows][1 pad + 64 px][16 ch]: the pad cell is column -1 of its row
+    // (minimal keys, written once).  (A 1.5-pixel stride makes the pooling reads conflict-free but measured slower: 11.3 vs 8.5 ms.)
+    __shared__ __attribute__((aligned(16))) unsigned short s_c[9 * 65 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
 #ifdef WG_TIMING
     long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
@@ -909,6 +911,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
         s_w[e] = f2bf((k < 36 && ci < 3) ? a.w[(j * 9 + tap) * 3 + ci] : 0.f);
     }
     for (int e = tid; e < C1P::NPIX * 4; e += 256) s_in[e] = 0;
+    if (tid < 9 * 8) ((unsigned*)s_c)[(tid >> 3) * 65 * 8 + (tid & 7)] = MI_KEY_MIN2;
     float bias4[4];                                        // output channels 4*kq .. 4*kq+3 (the MFMA's row quad)
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias4[r] = a.bias ? a.bias[kq * 4 + r] : 0.f;
@@ -951,52 +954,31 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
                 acc[m] = MFMA_BF16(bw2, __builtin_bit_cast(bf16x8, (uint4){t8.x, t8.y, 0u, 0u}), acc[m]);
             }
 #pragma unroll
-            for (int m = 0; m < C1P_GROUP; ++m)
-                *(uint2*)(s_c + ((wave * 9 + g0 + m) * 16 + i) * 16 + kq * 4) =
-                    (uint2){mi_pk_bf16(acc[m][0] + bias4[0], acc[m][1] + bias4[1]), mi_pk_bf16(acc[m][2] + bias4[2], acc[m][3] + bias4[3])};
+            for (int m = 0; m < C1P_GROUP; ++m) {
+                const int t = wave * 9 + g0 + m;                 // tiles 0..3 = conv row 0 of the item: outside the image when cy0 == -1
+                const bool dead = cy0 < 0 && t < 4;
+                const unsigned k0 = mi_bf16x2_to_keys(mi_pk_bf16(acc[m][0] + bias4[0], acc[m][1] + bias4[1]));
+                const unsigned k1 = mi_bf16x2_to_keys(mi_pk_bf16(acc[m][2] + bias4[2], acc[m][3] + bias4[3]));
+                *(uint2*)(s_c + (t * 16 + i + (t >> 2) + 1) * 16 + kq * 4) = (uint2){dead ? MI_KEY_MIN2 : k0, dead ? MI_KEY_MIN2 : k1};
+            }
         }
         TCK(5);
         __syncthreads();
         TCK(6);
-        {   // pooling: thread = (pooled row 0..3, pooled col 0..31, 8-channel half).  All 9 window reads are issued up
-            // front (clamped addresses); a window position outside the image (top row of the image, left column) is
-            // masked, and the first VALID position is always taken -- the rule of the stand-alone max-pool kernel.
+        {   // pooling: thread = (pooled row 0..3, pooled col 0..31, 8-channel half); 9 window reads, 4 v_max3_i32 per channel
             const int c8 = tid & 1, ox = (tid >> 1) & 31, oyl = tid >> 6;
-            const int ky0 = (cy0 + 2 * oyl < 0) ? 1 : 0, kx0 = (ox == 0) ? 1 : 0;
             uint4 u[9];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int x = 2 * ox - 1 + kx;
-                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * 64 + (x < 0 ? 0 : x)) * 16 + c8 * 8);
-                }
-            float best[8];
-            unsigned bi[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; bi[q] = 0; }
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bool valid = (ky >= ky0) && (kx >= kx0), isfirst = (ky == ky0) && (kx == kx0);
-                    const unsigned w[4] = {u[ky * 3 + kx].x, u[ky * 3 + kx].y, u[ky * 3 + kx].z, u[ky * 3 + kx].w};
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float v = (q & 1) ? __uint_as_float(w[q >> 1] & 0xffff0000u) : __uint_as_float(w[q >> 1] << 16);
-                        const bool take = valid & (isfirst | (v > best[q]) | (v != v));      // bitwise: selects, no control flow
-                        best[q] = take ? v : best[q];
-                        bi[q] = take ? (unsigned)(ky * 3 + kx) : bi[q];
-                    }
-                }
+                for (int kx = 0; kx < 3; ++kx)
+                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * 65 + 2 * ox + kx) * 16 + c8 * 8);
             const size_t o = ((((size_t)img * 32 + oy0 + oyl) * 32 + ox) * 2 + c8) * 8;
-            uint4 pk;                                        // best[] are bf16 values widened to fp32: the high halves are the bits
-            pk.x = (__float_as_uint(best[0]) >> 16) | (__float_as_uint(best[1]) & 0xffff0000u);
-            pk.y = (__float_as_uint(best[2]) >> 16) | (__float_as_uint(best[3]) & 0xffff0000u);
-            pk.z = (__float_as_uint(best[4]) >> 16) | (__float_as_uint(best[5]) & 0xffff0000u);
-            pk.w = (__float_as_uint(best[6]) >> 16) | (__float_as_uint(best[7]) & 0xffff0000u);
+            uint4 pk;
+            uint2 ar;
+            mi_pool9_keys(u, pk, ar);
             *(uint4*)(p_out + o) = pk;
-            *(uint2*)(p_arg + o) = (uint2){bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24)};
+            *(uint2*)(p_arg + o) = ar;
         }
         TCK(7);
     }

@@ -22,7 +22,8 @@ struct CpCfg {
     static constexpr int NK = (CIN == 32) ? 9 : 5, WS = NK * 32 + 16, W_ELEMS = COUT * WS;
     static constexpr int SCS = COUT + COUT / 2;                      // conv-output tile pixel stride (elements): 1.5 pixels -> the pooling
                                                                      // reads (lanes 2 pixels apart) hit every bank once
-    static constexpr int SC_ELEMS = CR * HW * SCS;                   // conv-output tile [row][col][channel]
+    static constexpr int SC_ELEMS = CR * (HW + 1) * SCS;             // conv-output tile [row][1 pad + col][channel] of order-preserving keys (common.h);
+                                                                     // the pad cell is column -1 of its row and holds minimal keys
     static constexpr int NMT = CR * HW / 16, MT = (NMT + 3) / 4, NB = COUT / 16, C8 = CIN / 8;
 #ifndef CP_MTC
 #define CP_MTC 3
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_bf16_kernel(ConvArgs a, 
     const unsigned short* g_in = (const unsigned short*)a.in;
     for (int e = tid; e < C::W_ELEMS / 8; e += 256) ((uint4*)s_w)[e] = ((const uint4*)a.wbank)[e];
     for (int e = tid; e < C::IN_ELEMS / 8; e += 256) ((uint4*)s_in)[e] = (uint4){0u, 0u, 0u, 0u};          // column halos stay zero
+    for (int e = tid; e < C::CR * (C::COUT / 2); e += 256) ((unsigned*)s_c)[(e / (C::COUT / 2)) * (C::HW + 1) * (C::SCS / 2) + e % (C::COUT / 2)] = MI_KEY_MIN2;
     float bias_r[C::NB][4];
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb)
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_bf16_kernel(ConvArgs a, 
         for (int mt0 = 0; mt0 < C::MT; mt0 += C::MTC) {
             f32x4 acc[C::MTC][C::NB];
             int abase[C::MTC], cbase[C::MTC];
+            bool dead[C::MTC];
 #pragma unroll
             for (int mt = 0; mt < C::MTC; ++mt) {
                 int t = wave + 4 * (mt0 + mt);
@@ -101,7 +104,8 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_bf16_kernel(ConvArgs a, 
                 t = live ? t : C::NMT - 1;
                 const int pl = t * 16 + i, y = pl / C::HW, x = pl % C::HW;
                 abase[mt] = (y * C::PW + x) * C::S;
-                cbase[mt] = live ? pl * C::SCS + kq * 4 : -1;
+                cbase[mt] = live ? (pl + y + 1) * C::SCS + kq * 4 : -1;
+                dead[mt] = cy0 < 0 && y == 0;                       // conv row -1 of the image: minimal keys
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -124,54 +128,31 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_bf16_kernel(ConvArgs a, 
             for (int mt = 0; mt < C::MTC; ++mt) {
                 if (cbase[mt] < 0) continue;
 #pragma unroll
-                for (int nb = 0; nb < C::NB; ++nb)
-                    *(uint2*)(s_c + cbase[mt] + nb * 16) =
-                        (uint2){mi_pk_bf16(acc[mt][nb][0] + bias_r[nb][0], acc[mt][nb][1] + bias_r[nb][1]),
-                                mi_pk_bf16(acc[mt][nb][2] + bias_r[nb][2], acc[mt][nb][3] + bias_r[nb][3])};
+                for (int nb = 0; nb < C::NB; ++nb) {
+                    const unsigned k0 = mi_bf16x2_to_keys(mi_pk_bf16(acc[mt][nb][0] + bias_r[nb][0], acc[mt][nb][1] + bias_r[nb][1]));
+                    const unsigned k1 = mi_bf16x2_to_keys(mi_pk_bf16(acc[mt][nb][2] + bias_r[nb][2], acc[mt][nb][3] + bias_r[nb][3]));
+                    *(uint2*)(s_c + cbase[mt] + nb * 16) = (uint2){dead[mt] ? MI_KEY_MIN2 : k0, dead[mt] ? MI_KEY_MIN2 : k1};
+                }
             }
         }
         __syncthreads();
-        // ---- pooling: thread = (pooled row 0..3, pooled col, 8-channel group).  The 9 window reads are issued up front
-        // (clamped addresses); a position outside the image (top row of the image, left column) is masked and the first
-        // VALID position is always taken -- the tie / NaN rule of the stand-alone max-pool kernel (misc.hip).
+        // ---- pooling: thread = (pooled row 0..3, pooled col, 8-channel group): 9 window reads of keys, 4 v_max3_i32 per channel
+        // (mi_pool9_keys, common.h); cells outside the image (row -1, column -1) hold minimal keys.
         if (tid < C::NPOOL) {
             constexpr int G8 = C::COUT / 8;
             const int c8 = tid % G8, ox = (tid / G8) % C::HO, oyl = tid / (G8 * C::HO);
-            const int ky0 = (cy0 + 2 * oyl < 0) ? 1 : 0, kx0 = (ox == 0) ? 1 : 0;
             uint4 u[9];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int x = 2 * ox - 1 + kx;
-                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * C::HW + (x < 0 ? 0 : x)) * C::SCS + c8 * 8);
-                }
-            float best[8];
-            unsigned bi[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; bi[q] = 0; }
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bool valid = (ky >= ky0) && (kx >= kx0), isfirst = (ky == ky0) && (kx == kx0);
-                    const unsigned w[4] = {u[ky * 3 + kx].x, u[ky * 3 + kx].y, u[ky * 3 + kx].z, u[ky * 3 + kx].w};
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float v = (q & 1) ? __uint_as_float(w[q >> 1] & 0xffff0000u) : __uint_as_float(w[q >> 1] << 16);
-                        const bool take = valid & (isfirst | (v > best[q]) | (v != v));      // bitwise: selects, no control flow
-                        best[q] = take ? v : best[q];
-                        bi[q] = take ? (unsigned)(ky * 3 + kx) : bi[q];
-                    }
-                }
+                for (int kx = 0; kx < 3; ++kx)
+                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * (C::HW + 1) + 2 * ox + kx) * C::SCS + c8 * 8);
             const size_t o = ((((size_t)img * C::HO + oy0 + oyl) * C::HO + ox) * G8 + c8) * 8;
-            uint4 pk;                                        // best[] are bf16 values widened to fp32: the high halves are the bits
-            pk.x = (__float_as_uint(best[0]) >> 16) | (__float_as_uint(best[1]) & 0xffff0000u);
-            pk.y = (__float_as_uint(best[2]) >> 16) | (__float_as_uint(best[3]) & 0xffff0000u);
-            pk.z = (__float_as_uint(best[4]) >> 16) | (__float_as_uint(best[5]) & 0xffff0000u);
-            pk.w = (__float_as_uint(best[6]) >> 16) | (__float_as_uint(best[7]) & 0xffff0000u);
+            uint4 pk;
+            uint2 ar;
+            mi_pool9_keys(u, pk, ar);
             *(uint4*)(p_out + o) = pk;
-            *(uint2*)(p_arg + o) = (uint2){bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24)};
+            *(uint2*)(p_arg + o) = ar;
         }
     }
 }
