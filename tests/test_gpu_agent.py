@@ -178,6 +178,39 @@ def test_cartpole_learns():
     assert last > 3 * first and last > 80
 
 
+def test_train_through_the_procgen_frame_source(tmp_path):
+    """SURVEY 8(f) row 1 end to end: a Procgen-shaped env (dict observations, 15 raw actions) behind ProcgenFrameSource drives
+    PPO.train with a validation env; the agent acts in the 9 reduced actions, Procgen's uint8 buffers go to the device as they
+    are, the stored frames are the env's bytes, and the checkpoint carries the reward normaliser's state."""
+    from test_env_pipeline import FakeProcgen
+    from agents.ppo import PPO
+    from common.env.procgen_pipeline import ProcgenFrameSource
+    from common.logger import Logger
+    from common.model import ImpalaModel
+    from common.policy import CategoricalPolicy
+    from common.storage import Storage
+    T, E = 8, 8
+    raw, raw_v = FakeProcgen(E, seed=5), FakeProcgen(E, seed=6)
+    env, env_v = ProcgenFrameSource(raw), ProcgenFrameSource(raw_v)
+    assert env.action_space.n == 9
+    torch.manual_seed(0)
+    policy = CategoricalPolicy(ImpalaModel(3), False, env.action_space.n)
+    dev = torch.device("cuda", 0)
+    storage, storage_v = Storage((3, 64, 64), 256, T, E, dev), Storage((3, 64, 64), 256, T, E, dev)
+    logger = Logger(E, str(tmp_path))
+    agent = PPO(env, policy, logger, storage, dev, 1, env_valid=env_v, storage_valid=storage_v, n_steps=T, n_envs=E, epoch=1,
+                n_minibatch=2, mini_batch_size=32, gamma=0.999, lmbda=0.95, learning_rate=5e-4, seed=0, precision="bf16")
+    agent.train(3 * T * E - 1)             # checkpoints are written when t EXCEEDS the mark (agents/ppo.py:271)
+    assert len(raw.received) == 3 * T and all(a.dtype == np.int32 and a.max() < 15 for a in raw.received)
+    assert set(np.unique(np.concatenate(raw.received))) <= {0, 1, 2, 3, 4, 5, 6, 7, 8}           # first indices of the 9 unique names
+    rew = storage.rew_batch.numpy()
+    assert np.abs(rew).max() <= 10.0 and np.isfinite(logger.rows[-1][logger.columns.index("loss_total")])
+    ck = [f for f in os.listdir(tmp_path) if f.endswith(".pth")]
+    assert len(ck) == 1
+    state = torch.load(os.path.join(tmp_path, ck[0]), weights_only=True)
+    assert state["t"] == 3 * T * E and state["reward_norm"]["count"] == pytest.approx(1e-4 + 3 * T * E) and state["reward_norm"]["var"] > 0
+
+
 _TWO_RANK = r'''
 import os, sys, numpy as np, torch, torch.distributed as dist
 rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]

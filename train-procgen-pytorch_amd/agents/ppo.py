@@ -245,8 +245,12 @@ class PPO(BaseAgent):
             if checkpoint_cnt < len(checkpoints) and self.t > checkpoints[checkpoint_cnt]:
                 if self.coll.rank == 0:
                     print("Saving model.")
+                    # the reference's two keys (agents/ppo.py:271-276) + what it forgets and a resume needs: the step counter, the
+                    # learning rate and the reward normaliser's running variance (extra keys are ignored by the reference's loaders)
+                    rs = getattr(self.env, "reward_state", None)
                     torch.save({'model_state_dict': self.policy.state_dict(),
-                                'optimizer_state_dict': self.optimizer.state_dict()},
+                                'optimizer_state_dict': self.optimizer.state_dict(),
+                                't': int(self.t), 'learning_rate': float(lr), 'reward_norm': rs() if callable(rs) else None},
                                self.logger.logdir + '/model_' + str(self.t) + '.pth')
                 checkpoint_cnt += 1
         self.env.close()

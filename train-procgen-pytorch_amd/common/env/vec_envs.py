@@ -86,10 +86,7 @@ class SyntheticFrames:
         pass
 
 
-def create_procgen_env(*args, **kwargs):
-    try:
-        import procgen  # noqa: F401
-    except ImportError as e:
-        raise NotImplementedError("the Procgen C++ engine (procgen==0.10.7) is not installed in this image; "
-                                  "use --env_name synthetic or cartpole") from e
-    raise NotImplementedError("Procgen wrapper chain -> uint8 NHWC producer is the next row of SURVEY 8(f)")
+def create_procgen_env(**kwargs):
+    """The Procgen engine behind the one-object wrapper chain of common/env/procgen_pipeline.py (uint8 NHWC frames out)."""
+    from common.env.procgen_pipeline import create_procgen_env as make
+    return make(**kwargs)

@@ -46,17 +46,30 @@ def add_training_args(p):
     p.add_argument('--use_valid_env', action="store_true", default=True)
     p.add_argument('--no-use_valid_env', dest='use_valid_env', action="store_false")
     p.add_argument('--use_wandb', action="store_true")
+    p.add_argument('--val_env_name', type=str, default=None)
+    p.add_argument('--start_level', type=int, default=0)
+    p.add_argument('--num_levels', type=int, default=500)
+    p.add_argument('--distribution_mode', type=str, default='hard')
+    p.add_argument('--num_threads', type=int, default=8)
+    p.add_argument('--reduce_duplicate_actions', action="store_true", default=True)
+    p.add_argument('--no-reduce_duplicate_actions', dest='reduce_duplicate_actions', action="store_false")
     # (new) IMPALA activation storage / matrix-core type: fp32 = the parity mode, bf16 = BASELINE config 3 (what bench.py measures)
     p.add_argument('--precision', type=str, default=None, choices=['fp32', 'bf16'])
     return p
 
 
-def make_env(env_name, n_envs, seed, A):
+def make_env(env_name, n_envs, seed, A, args=None, hp=None, is_valid=False):
     if env_name == "synthetic":
         return SyntheticFrames(n_envs, A, seed)
     if env_name.startswith("cartpole"):
         return CartPoleVec(n_envs, seed=seed)
-    return create_procgen_env(env_name=env_name, n_envs=n_envs)
+    hp = hp or {}
+    return create_procgen_env(env_name=env_name, n_envs=n_envs, is_valid=is_valid, val_env_name=getattr(args, "val_env_name", None),
+                              start_level=getattr(args, "start_level", 0), num_levels=getattr(args, "num_levels", 500),
+                              distribution_mode=getattr(args, "distribution_mode", "hard"), num_threads=getattr(args, "num_threads", 8),
+                              paint_vel_info=hp.get("paint_vel_info", True), normalize_rew=hp.get("normalize_rew", True),
+                              mirror_env=hp.get("mirror_env", False),
+                              reduce_duplicate_actions=getattr(args, "reduce_duplicate_actions", True))
 
 
 def initialize_model(device, env, hp):
@@ -85,8 +98,8 @@ def train_ppo(args):
     device = torch.device("cuda", args.gpu_device)
     n_envs, n_steps = hp.get("n_envs", 256), hp.get("n_steps", 256)
     A = 15 if hp.get("architecture", "impala") == "impala" else 2
-    env = make_env(args.env_name, n_envs, args.seed, A)
-    env_valid = make_env(args.env_name, n_envs, args.seed + 1, A) if args.use_valid_env else None
+    env = make_env(args.env_name, n_envs, args.seed, A, args, hp)
+    env_valid = make_env(args.env_name, n_envs, args.seed + 1, A, args, hp, is_valid=True) if args.use_valid_env else None
     logdir = os.path.join('logs', 'train', args.env_name, args.exp_name, time.strftime("%Y-%m-%d__%H-%M-%S") + f'__seed_{args.seed}')
     os.makedirs(logdir, exist_ok=True)
     np.save(os.path.join(logdir, "hyperparameters.npy"), hp)
@@ -101,6 +114,8 @@ def train_ppo(args):
         ck = torch.load(args.model_file, map_location="cpu", weights_only=True)
         agent.policy.load_state_dict(ck["model_state_dict"])
         agent.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        if ck.get("reward_norm") and getattr(env, "_rew", None) is not None:
+            env._rew.load_state(ck["reward_norm"])
     agent.train(args.num_timesteps)
     return agent
 
