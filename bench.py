@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--profile-rollout", action="store_true", help="bracket the rollout-phase launches with HIP events too")
     ap.add_argument("--no-kernel-profile", action="store_true", help="diagnostic: no HIP events around the launches (roofline = null)")
     ap.add_argument("--profile-period", type=int, default=8, help="bracket every P-th minibatch update with HIP events (1 = all)")
+    ap.add_argument("--rank-share", type=int, default=1, help="diagnostic: on ONE GPU, run the launch sizes a rank of an R-GPU job sees "
+                    "(minibatches of mini_batch_size/R, R-fold gradient accumulation, no collectives)")
     ap.add_argument("--h2d", action="store_true", help="also upload the E frames of every rollout step from pinned host memory")
     args = ap.parse_args()
 
@@ -185,6 +187,8 @@ def main():
 
     hp = yaml.safe_load(open(os.path.join(PKG, "hyperparams", "procgen", "config.yml")))[args.param_name]
     T, E, A = hp["n_steps"], hp["n_envs"], 15
+    if args.rank_share > 1:
+        hp["mini_batch_size"] //= args.rank_share
     torch.manual_seed(6033)
     model = ImpalaModel(in_channels=3)
     policy = CategoricalPolicy(model, False, A)

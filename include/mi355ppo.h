@@ -132,6 +132,13 @@ int mi_adv_apply(mi_ctx* ctx, const double stats3[3]);
  *      (= n_idx on one GPU).  Appends one 8-float record to the device loss log:
  *      {pi_loss, value_loss, entropy, x_ent, total, feature_sparsity, marginal_entropy, 0}. */
 int mi_minibatch(mi_ctx* ctx, const int64_t* idx, int32_t n_idx, int32_t n_global, const mi_hparams* hp);
+/* gradient accumulation (agents/ppo.py:155-177: the gradients of batch_size / mini_batch_size minibatches are SUMMED before one
+ * optimizer step) in one pass: idx holds the gathered samples of n_seg minibatches back to back (seg_n[k] entries each, sum =
+ * n_idx <= max_batch), every one a global minibatch of n_global samples.  Same gradients up to fp32 summation order, one log
+ * record per segment; needs x_entropy_coef == 0 and fs_coef == 0 (no batch-level loss term) and multirank mode 0 or 2.  On R ranks
+ * a rank's share of a global minibatch is ~1/R of it: this keeps its launches at single-GPU size. */
+int mi_minibatch_multi(mi_ctx* ctx, const int64_t* idx, int32_t n_idx, const int32_t* seg_n, int32_t n_seg, int32_t n_global,
+                       const mi_hparams* hp);
 /* clip_grad_norm_ + Adam.step + zero_grad (agents/ppo.py:174-176); adam_step = 1-based step count */
 int mi_optimizer_step(mi_ctx* ctx, float lr, float max_grad_norm, int32_t adam_step, float* grad_norm_out);
 int mi_loss_log_read(mi_ctx* ctx, float* out, int32_t max_records, int32_t* n_records, int32_t reset);

@@ -44,6 +44,7 @@ class PPO(BaseAgent):
         self.normalize_adv, self.normalize_rew, self.use_gae = normalize_adv, normalize_rew, use_gae
         self.adjust_lr = adjust_lr_grok if increasing_lr else adjust_lr
         self.seed = int(kwargs.get("seed", 0))
+        self.merge_accumulation = bool(kwargs.get("merge_accumulation", True))      # (new) see optimize()
         # activation storage of the IMPALA path: "fp32" (parity mode) or "bf16" (BASELINE config 3)
         self.precision = kwargs.get("precision", "fp32") if policy.arch == "impala" else "fp32"
 
@@ -51,7 +52,13 @@ class PPO(BaseAgent):
         self.coll = Collective()
         self.n_envs_global = n_envs * self.coll.world
         n_total = n_steps * self.n_envs_global
-        max_local = min(mini_batch_size, n_total // n_minibatch)
+        batch_size = n_total // n_minibatch
+        max_local = min(mini_batch_size, batch_size)               # worst case for ONE minibatch: all of it in this rank's shard
+        if self.merge_accumulation and batch_size > max_local and x_entropy_coef == 0 and fs_coef == 0:
+            # accumulated minibatches are processed together (optimize()): room for this rank's expected share of the samples
+            # between two optimizer steps (+7 % + 64: > 6 sigma of the split of a random permutation over the ranks), capped
+            share = -(-batch_size // self.coll.world)
+            max_local = max(max_local, min(16384 if self.precision == "bf16" else 8192, int(share * 1.07) + 64, n_steps * n_envs))
         dev_index = device.index if isinstance(device, torch.device) and device.index is not None else 0
         arch = policy.arch
         emb = policy.embedder
@@ -164,25 +171,48 @@ class PPO(BaseAgent):
         # Multi-rank: the backward pass needs a cross-rank statistic (the batch-mean action distribution) only for the x-entropy
         # term; without it (and without the feature-sparsity term) every rank runs its minibatches straight through and the
         # logged loss sums are reduced over the ranks ONCE per optimize() instead of once per minibatch.
-        deferred = coll.active and self.x_entropy_coef == 0 and self.fs_coef == 0
+        no_batch_terms = self.x_entropy_coef == 0 and self.fs_coef == 0
+        deferred = coll.active and no_batch_terms
+        # Gradient accumulation (grad_accumulation_steps > 1: the gradients of that many minibatches are summed before one optimizer
+        # step, :170-177) without batch-level loss terms is one sum over all their samples: this rank's shares of the accumulated
+        # minibatches go through the network in ONE pass (mi_minibatch_multi; losses still taken and logged per minibatch).  On R
+        # ranks a share is ~1/R of a minibatch, so this keeps every launch at single-GPU size instead of R-fold smaller.
+        merge = self.merge_accumulation and no_batch_terms and grad_accumulation_steps > 1
         n_mb = 0
         if coll.active:
             eng.set_multirank(2 if deferred else 1)
+        held, held_n, held_global = [], 0, self.mini_batch_size
+
+        def flush():
+            nonlocal held, held_n
+            if held:
+                eng.minibatch_multi(np.concatenate(held), [len(h) for h in held], held_global, hp)
+            held, held_n = [], 0
+
         for _ in range(self.epoch):
             for chunk in self.storage.minibatch_index_stream(self.mini_batch_size, recurrent, self.n_envs_global):
                 local = shard_indices(chunk, self.n_envs_global, coll.rank, coll.world)
-                eng.minibatch(local, len(chunk), hp)
                 n_mb += 1
-                if coll.active and not deferred:
-                    with torch.cuda.stream(self._tstream):
-                        coll.allreduce_sum_(self._stats_t)   # 32 floats: loss sums + mean action probabilities
-                    eng.minibatch_finish()
+                if merge:
+                    if held_n + len(local) > eng.max_batch or len(held) == 16 or (held and len(chunk) != held_global):
+                        flush()
+                    held.append(local)
+                    held_n += len(local)
+                    held_global = len(chunk)
+                else:
+                    eng.minibatch(local, len(chunk), hp)
+                    if coll.active and not deferred:
+                        with torch.cuda.stream(self._tstream):
+                            coll.allreduce_sum_(self._stats_t)   # 32 floats: loss sums + mean action probabilities
+                        eng.minibatch_finish()
                 if cnt % grad_accumulation_steps == 0:
+                    flush()
                     if coll.active:
                         with torch.cuda.stream(self._tstream):
                             coll.allreduce_sum_(self._grads_t)   # ONE collective per optimizer step: the flat gradient
                     self.optimizer.step(self.grad_clip_norm)
                 cnt += 1
+        flush()
         if deferred:
             with torch.cuda.stream(self._tstream):
                 coll.allreduce_sum_(self._ring_t[:32 * n_mb])

@@ -170,6 +170,15 @@ void launch_logp_all(const float* hout, int n, int A, float* lp_out, float* valu
 void gemm_set_workspace(float* ws, size_t floats);
 void colsum_set_workspace(float* ws);   // >= 64 * max_N floats
 void launch_loss_bwd(const LossArgs& a, hipStream_t st);
+// several global minibatches in one gathered batch (mi_minibatch_multi): samples of segment k are [start[k], start[k+1])
+constexpr int MI_MAX_SEG = 16;
+struct SegTab { int n_seg; int start[MI_MAX_SEG + 1]; };
+int  loss_blocks_seg(const SegTab& st);
+void launch_loss_fwd_seg(const LossArgs& a, const SegTab& st, hipStream_t stream);
+// one workgroup per segment: its block partials -> stats_base + 32 k (phase bit 0), derived terms + record log_base + 8 k (bit 1, fs_base[k])
+void launch_loss_finalize_seg(const LossArgs& a, const SegTab& st, int phase, float* stats_base, const float* fs_base, float* log_base, hipStream_t stream);
+// colmax_scratch: n_seg x 128 x d floats; fs_out[k] = the feature-sparsity metric of segment k
+void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, float* fs_out, hipStream_t stream);
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st);
 
 void launch_gae(const float* rew, const float* done, const float* value, float* adv, float* ret, int T, int E,

@@ -288,7 +288,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         }
         HIPC(dalloc(&c->slabs, c->slab_floats));
         HIPC(hipMalloc((void**)&c->d_slab_desc, sizeof(SlabDesc) * 15)); c->slab_desc_n = 0; c->slab_desc_cached_n = -1;
-        HIPC(dalloc(&c->fs_scratch, (size_t)128 * 2048));      // FS_GROUPS x 2048 partial column maxima (misc.hip)
+        HIPC(dalloc(&c->fs_scratch, (size_t)MI_MAX_SEG * 128 * 2048));      // (segments x) FS_GROUPS x 2048 partial column maxima (misc.hip)
     } else {
         c->obs_bytes_per_env = (size_t)cfg->obs_dim * sizeof(float);
         HIPC(dalloc(&c->obsf, (size_t)(T + 1) * E * cfg->obs_dim));
@@ -321,7 +321,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         HIPC(hipMemcpy(c->lut16, b.data(), 512, hipMemcpyHostToDevice));
     }
     HIPC(dalloc(&c->d_idx, (size_t)NB));
-    HIPC(dalloc(&c->loss_partial, (size_t)(loss_blocks(NB) + 1) * 32));
+    HIPC(dalloc(&c->loss_partial, (size_t)(loss_blocks(NB) + 1 + MI_MAX_SEG) * 32));
     HIPC(dalloc(&c->loss_stats, 64));
     c->log_cap = 4096; c->log_count = 0;
     HIPC(dalloc(&c->loss_log, (size_t)c->log_cap * 8));
@@ -1085,11 +1085,19 @@ static InputSrc minibatch_src(mi_ctx* c) {
     return InputSrc{c->frames ? (const void*)c->frames : (const void*)c->obsf, c->d_idx, 0};
 }
 
-int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, const mi_hparams* hp) {
+// One forward + backward pass over n gathered samples that belong to n_seg GLOBAL minibatches (segment k = seg_n[k] consecutive
+// entries of idx, every segment a global minibatch of n_global samples): per-sample gradients scale with 1 / n_global, the loss
+// statistics are taken and logged per segment.  n_seg > 1 is gradient accumulation done in one launch set (agents/ppo.py:170-177
+// sums the gradients of the accumulated minibatches before the optimizer step, so only the fp32 summation order changes); it
+// needs a loss without batch-level terms (x_entropy_coef == 0, fs_coef == 0).
+static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_t* seg_n, int32_t n_seg, int32_t n_global, const mi_hparams* hp) {
     ARG(c && hp, "null"); ARG(n >= 0 && n <= c->NB, "n_idx must be in [0, max_batch]"); ARG(n_global >= 1, "n_global");
-    ARG(n == 0 || idx, "idx");
-    ARG(c->log_count < c->log_cap, "loss log full: call mi_loss_log_read(reset=1)");
+    ARG(n == 0 || idx, "idx"); ARG(n_seg >= 1 && n_seg <= MI_MAX_SEG && seg_n, "1 .. 16 segments");
+    ARG(c->log_count + n_seg <= c->log_cap, "loss log full: call mi_loss_log_read(reset=1)");
     ARG(c->pending_n < 0, "previous multirank minibatch not finished");
+    { long long tot = 0; for (int k = 0; k < n_seg; ++k) { ARG(seg_n[k] >= 0, "negative segment"); tot += seg_n[k]; } ARG(tot == n, "segments do not add up to n_idx"); }
+    const bool batch_terms = hp->x_entropy_coef != 0.f || hp->fs_coef != 0.f;
+    ARG(n_seg == 1 || (!batch_terms && c->multirank != 1), "several minibatches per call need x_entropy_coef == 0, fs_coef == 0 and multirank mode 0 or 2");
     const int64_t TE = (int64_t)c->T * c->E;
     for (int k = 0; k < n; ++k) ARG(idx[k] >= 0 && idx[k] < TE, "minibatch index out of range");
     if (n) {
@@ -1107,40 +1115,59 @@ int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, con
     c->prof.sample_now = (c->prof.mb_count++ % c->prof.period) == 0;
     net_forward(c, src, n, false, true, true);
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
-    if (impala) launch_fs_metric(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_val, c->stream);
     LossArgs a{};
     a.hout = c->hout; a.idx = c->d_idx; a.act = c->act; a.old_logp = c->logp; a.old_value = c->value; a.ret = c->ret; a.adv = c->adv;
     a.dY = c->dY; a.partial = c->loss_partial; a.stats = c->loss_stats; a.n = n; a.A = c->A;
     a.inv_n_global = 1.0f / (float)n_global;
     a.hp = LossHP{hp->eps_clip, hp->value_coef, hp->entropy_coef, hp->x_entropy_coef, hp->entropy_multiplier, hp->fs_coef};
-    launch_loss_fwd(a, c->stream);
-    float* slot = c->loss_log + (size_t)c->log_count * 8;
-    if (c->multirank == 2) {
+    if (c->multirank == 2)
         // deferred statistics: nothing in the backward pass needs the cross-rank sums when x_entropy_coef == 0 and fs_coef == 0, so this
         // rank's partial sums go to ring slot log_count and are summed over the ranks ONCE per optimize() (mi_loss_log_finalize)
-        ARG(hp->x_entropy_coef == 0.f && hp->fs_coef == 0.f, "multirank mode 2 needs x_entropy_coef == 0 and fs_coef == 0 (use mode 1)");
-        LossArgs r = a; r.stats = c->stats_ring + (size_t)c->log_count * 32;
-        launch_loss_finalize(r, loss_blocks(n), 1, nullptr, nullptr, c->stream);
-        if (impala) HIPC(hipMemcpyAsync(c->fs_ring + c->log_count, c->fs_val, 4, hipMemcpyDeviceToDevice, c->stream));
+        ARG(!batch_terms, "multirank mode 2 needs x_entropy_coef == 0 and fs_coef == 0 (use mode 1)");
+    if (n_seg > 1) {
+        // loss terms + logged statistics of all segments with one launch each (modes 0 and 2 only): the rank-local sums land in the
+        // statistics ring (mode 0 derives the records right away, mode 2 after the cross-rank sum in mi_loss_log_finalize)
+        SegTab st{};
+        st.n_seg = n_seg;
+        for (int k = 0; k < n_seg; ++k) st.start[k + 1] = st.start[k] + seg_n[k];
+        float* ring = c->stats_ring + (size_t)c->log_count * 32;
+        float* fsr = c->fs_ring + c->log_count;
+        if (impala) launch_fs_metric_seg(c->blk[2].P2, c->bf, st, 2048, c->fs_scratch, fsr, c->stream);
+        launch_loss_fwd_seg(a, st, c->stream);
+        launch_loss_finalize_seg(a, st, c->multirank == 2 ? 1 : 3, ring, impala ? fsr : nullptr,
+                                 c->multirank == 2 ? nullptr : c->loss_log + (size_t)c->log_count * 8, c->stream);
         c->ring_args = a;
-        c->log_count++;
-        launch_loss_bwd(a, c->stream);
-        net_backward(c, src, n);
-        HIPC(hipGetLastError());
-        return 0;
+        c->log_count += n_seg;
+    } else {
+        if (impala) launch_fs_metric(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_val, c->stream);
+        launch_loss_fwd(a, c->stream);
+        if (c->multirank == 2) {
+            LossArgs g = a; g.stats = c->stats_ring + (size_t)c->log_count * 32;
+            launch_loss_finalize(g, loss_blocks(n), 1, nullptr, nullptr, c->stream);
+            if (impala) HIPC(hipMemcpyAsync(c->fs_ring + c->log_count, c->fs_val, 4, hipMemcpyDeviceToDevice, c->stream));
+            c->ring_args = a;
+            c->log_count++;
+        } else if (c->multirank == 1) {
+            launch_loss_finalize(a, loss_blocks(n), 1, nullptr, nullptr, c->stream);
+            c->pending = a; c->pending_n = n;
+            HIPC(hipGetLastError());
+            return 0;                                   // host all-reduces loss_stats, then mi_minibatch_finish
+        } else {
+            launch_loss_finalize(a, loss_blocks(n), 3, impala ? c->fs_val : nullptr, c->loss_log + (size_t)c->log_count * 8, c->stream);
+            c->log_count++;
+        }
     }
-    if (c->multirank) {
-        launch_loss_finalize(a, loss_blocks(n), 1, nullptr, nullptr, c->stream);
-        c->pending = a; c->pending_n = n;
-        HIPC(hipGetLastError());
-        return 0;                                   // host all-reduces loss_stats, then mi_minibatch_finish
-    }
-    launch_loss_finalize(a, loss_blocks(n), 3, impala ? c->fs_val : nullptr, slot, c->stream);
-    c->log_count++;
     launch_loss_bwd(a, c->stream);
     net_backward(c, src, n);
     HIPC(hipGetLastError());
     return 0;
+}
+
+int mi_minibatch(mi_ctx* c, const int64_t* idx, int32_t n, int32_t n_global, const mi_hparams* hp) {
+    return minibatch_impl(c, idx, n, &n, 1, n_global, hp);
+}
+int mi_minibatch_multi(mi_ctx* c, const int64_t* idx, int32_t n, const int32_t* seg_n, int32_t n_seg, int32_t n_global, const mi_hparams* hp) {
+    return minibatch_impl(c, idx, n, seg_n, n_seg, n_global, hp);
 }
 
 int mi_set_multirank(mi_ctx* c, int32_t enabled) { ARG(c, "null"); ARG(enabled >= 0 && enabled <= 2, "mode"); c->multirank = enabled; return 0; }

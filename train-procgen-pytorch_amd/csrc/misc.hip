@@ -496,25 +496,52 @@ __device__ __forceinline__ void sample_terms(const LossArgs& a, int s, SampleTer
 
 int loss_blocks(int n) { return (n + 255) / 256; }
 
-__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a) {
+// one 256-sample block of the loss: sums over the samples s < s_end of this block -> partial row `row`
+__device__ __forceinline__ void loss_fwd_block(const LossArgs& a, int s, int s_end, int row) {
     __shared__ float sb[4];
-    const int s = blockIdx.x * 256 + threadIdx.x;
     SampleTerms t;
     float pi = 0.f, vm = 0.f, H = 0.f;
     float pa[MAXA];
     for (int k = 0; k < MAXA; ++k) pa[k] = 0.f;
-    if (s < a.n) {
+    if (s < s_end) {
         sample_terms(a, s, t);
         pi = fminf(t.surr1, t.surr2);
         vm = fmaxf(t.vs1, t.vs2);
         H = t.H;
         for (int k = 0; k < a.A; ++k) pa[k] = t.p[k];
     }
-    float* out = a.partial + (long long)blockIdx.x * (8 + a.A);
+    float* out = a.partial + (long long)row * (8 + a.A);
     float r = block_sum256(pi, sb); if (threadIdx.x == 0) out[0] = r;
     r = block_sum256(vm, sb);       if (threadIdx.x == 0) out[1] = r;
     r = block_sum256(H, sb);        if (threadIdx.x == 0) out[2] = r;
     for (int k = 0; k < a.A; ++k) { r = block_sum256(pa[k], sb); if (threadIdx.x == 0) out[8 + k] = r; }
+}
+__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a) {
+    loss_fwd_block(a, blockIdx.x * 256 + threadIdx.x, a.n, blockIdx.x);
+}
+// segment k owns ceil(len_k / 256) consecutive blocks (no block straddles two minibatches)
+__device__ __forceinline__ void seg_of_block(const SegTab& st, int b, int& k, int& first) {
+    first = 0;
+    for (k = 0; k < st.n_seg - 1; ++k) {
+        const int nb = (st.start[k + 1] - st.start[k] + 255) / 256;
+        if (b < first + nb) break;
+        first += nb;
+    }
+}
+__global__ __launch_bounds__(256) void loss_fwd_seg_kernel(LossArgs a, SegTab st) {
+    int k, first;
+    seg_of_block(st, blockIdx.x, k, first);
+    loss_fwd_block(a, st.start[k] + (blockIdx.x - first) * 256 + threadIdx.x, st.start[k + 1], blockIdx.x);
+}
+int loss_blocks_seg(const SegTab& st) {
+    int nb = 0;
+    for (int k = 0; k < st.n_seg; ++k) nb += (st.start[k + 1] - st.start[k] + 255) / 256;
+    return nb;
+}
+void launch_loss_fwd_seg(const LossArgs& a, const SegTab& st, hipStream_t stream) {
+    const int nb = loss_blocks_seg(st);
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(loss_fwd_seg_kernel, dim3(nb), dim3(256), 0, stream, a, st);
 }
 void launch_loss_fwd(const LossArgs& a, hipStream_t st) {
     if (a.n <= 0) return;
@@ -523,7 +550,7 @@ void launch_loss_fwd(const LossArgs& a, hipStream_t st) {
 
 // phase 1: block partials -> this rank's contribution to the GLOBAL-minibatch means (x inv_n_global)
 // phase 2: (after the optional cross-rank sum of stats[0..2], stats[8..8+A)) derived terms + log record
-__global__ void loss_finalize_kernel(LossArgs a, int nblk, int phase, const float* fs_ptr, float* log_slot) {
+__device__ __forceinline__ void loss_finalize_body(const LossArgs& a, int nblk, int phase, const float* fs_ptr, float* log_slot) {
     const int k = threadIdx.x;
     if (phase & 1) {
         if (k < 3 || (k >= 8 && k < 8 + a.A)) {
@@ -549,6 +576,20 @@ __global__ void loss_finalize_kernel(LossArgs a, int nblk, int phase, const floa
             log_slot[4] = total; log_slot[5] = fs; log_slot[6] = marg; log_slot[7] = 0.f;
         }
     }
+}
+__global__ void loss_finalize_kernel(LossArgs a, int nblk, int phase, const float* fs_ptr, float* log_slot) {
+    loss_finalize_body(a, nblk, phase, fs_ptr, log_slot);
+}
+__global__ void loss_finalize_seg_kernel(LossArgs a, SegTab st, int phase, float* stats_base, const float* fs_base, float* log_base) {
+    const int k = blockIdx.x;
+    int first = 0;
+    for (int j = 0; j < k; ++j) first += (st.start[j + 1] - st.start[j] + 255) / 256;
+    a.partial += (long long)first * (8 + a.A);
+    a.stats = stats_base + 32 * k;
+    loss_finalize_body(a, (st.start[k + 1] - st.start[k] + 255) / 256, phase, fs_base ? fs_base + k : nullptr, log_base ? log_base + 8 * k : nullptr);
+}
+void launch_loss_finalize_seg(const LossArgs& a, const SegTab& st, int phase, float* stats_base, const float* fs_base, float* log_base, hipStream_t stream) {
+    hipLaunchKernelGGL(loss_finalize_seg_kernel, dim3(st.n_seg), dim3(64), 0, stream, a, st, phase, stats_base, fs_base, log_base);
 }
 void launch_loss_finalize(const LossArgs& a, int nblk, int phase, const float* fs_ptr, float* log_slot, hipStream_t st) {
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a, nblk, phase, fs_ptr, log_slot);
@@ -627,6 +668,49 @@ __global__ __launch_bounds__(1024) void fs_finalize_kernel(const float* part, in
     if ((threadIdx.x & 63) == 0) sb[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) { double tot = 0.0; for (int k = 0; k < 16; ++k) tot += sb[k]; fs_out[0] = (float)(tot / d); }
+}
+__global__ __launch_bounds__(256) void colmax_partial_seg_kernel(const void* x, int bf16, SegTab st, int d, float* part) {
+    const int k = blockIdx.y, r0 = st.start[k], r1 = st.start[k + 1];
+    for (int j = threadIdx.x * 8; j < d; j += 256 * 8) {
+        float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = r0 + blockIdx.x; b < r1; b += FS_GROUPS) {
+            const long long o = (long long)b * d + j;
+            if (bf16) {
+                const uint4 u = *(const uint4*)((const unsigned short*)x + o);
+                const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (q & 1) ? __uint_as_float(w[q >> 1] & 0xffff0000u) : __uint_as_float(w[q >> 1] << 16));
+            } else {
+                const f32x4 lo = *(const f32x4*)((const float*)x + o), hi = *(const f32x4*)((const float*)x + o + 4);
+                m[0] = fmaxf(m[0], lo.x); m[1] = fmaxf(m[1], lo.y); m[2] = fmaxf(m[2], lo.z); m[3] = fmaxf(m[3], lo.w);
+                m[4] = fmaxf(m[4], hi.x); m[5] = fmaxf(m[5], hi.y); m[6] = fmaxf(m[6], hi.z); m[7] = fmaxf(m[7], hi.w);
+            }
+        }
+        float* p = part + ((long long)k * FS_GROUPS + blockIdx.x) * d + j;
+        *(f32x4*)p = (f32x4){m[0], m[1], m[2], m[3]};
+        *(f32x4*)(p + 4) = (f32x4){m[4], m[5], m[6], m[7]};
+    }
+}
+__global__ __launch_bounds__(1024) void fs_finalize_seg_kernel(const float* part, int groups, int d, float* fs_out) {
+    __shared__ double sb[16];
+    part += (long long)blockIdx.x * groups * d;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < d; j += 1024) {
+        float m = 0.f;
+#pragma unroll 16
+        for (int g = 0; g < groups; ++g) m = fmaxf(m, part[(long long)g * d + j]);
+        s += (double)tanhf(fabsf(m * 100.f));
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sb[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double tot = 0.0; for (int k = 0; k < 16; ++k) tot += sb[k]; fs_out[blockIdx.x] = (float)(tot / d); }
+}
+void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, float* fs_out, hipStream_t stream) {
+    if (st.n_seg <= 0) return;
+    if (d % 8) abort();
+    hipLaunchKernelGGL(colmax_partial_seg_kernel, dim3(FS_GROUPS, st.n_seg), dim3(256), 0, stream, flat_pre, bf16, st, d, colmax_scratch);
+    hipLaunchKernelGGL(fs_finalize_seg_kernel, dim3(st.n_seg), dim3(1024), 0, stream, (const float*)colmax_scratch, FS_GROUPS, d, fs_out);
 }
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st) {
     if (n <= 0) return;

@@ -40,7 +40,7 @@ def lib_path():
 EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_param_count mi_set_params "
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
            "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
-           "mi_adv_stats mi_adv_apply mi_minibatch mi_optimizer_step mi_loss_log_read mi_device_ptr "
+           "mi_adv_stats mi_adv_apply mi_minibatch mi_minibatch_multi mi_optimizer_step mi_loss_log_read mi_device_ptr "
            "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
 
 
@@ -288,6 +288,12 @@ class Engine:
     def minibatch(self, idx, n_global, hp):
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         self._chk(self.lib.mi_minibatch(self._ctx, _fp(idx), C.c_int32(idx.size), C.c_int32(n_global), C.byref(hp)))
+
+    def minibatch_multi(self, idx, seg_n, n_global, hp):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        seg = np.ascontiguousarray(seg_n, dtype=np.int32)
+        self._chk(self.lib.mi_minibatch_multi(self._ctx, _fp(idx), C.c_int32(idx.size), seg.ctypes.data_as(C.c_void_p), C.c_int32(seg.size),
+                                              C.c_int32(n_global), C.byref(hp)))
 
     def minibatch_finish(self):
         self._chk(self.lib.mi_minibatch_finish(self._ctx))
