@@ -172,13 +172,17 @@ void colsum_set_workspace(float* ws);   // >= 64 * max_N floats
 void launch_loss_bwd(const LossArgs& a, hipStream_t st);
 // several global minibatches in one gathered batch (mi_minibatch_multi): samples of segment k are [start[k], start[k+1])
 constexpr int MI_MAX_SEG = 16;
+constexpr int FS_PARTS = 8;           // column blocks of the feature-sparsity metric's second stage
 struct SegTab { int n_seg; int start[MI_MAX_SEG + 1]; };
 int  loss_blocks_seg(const SegTab& st);
-void launch_loss_fwd_seg(const LossArgs& a, const SegTab& st, hipStream_t stream);
-// one workgroup per segment: its block partials -> stats_base + 32 k (phase bit 0), derived terms + record log_base + 8 k (bit 1, fs_base[k])
-void launch_loss_finalize_seg(const LossArgs& a, const SegTab& st, int phase, float* stats_base, const float* fs_base, float* log_base, hipStream_t stream);
-// colmax_scratch: n_seg x 128 x d floats; fs_out[k] = the feature-sparsity metric of segment k
-void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, float* fs_out, hipStream_t stream);
+// with_bwd: also writes dY (the loss_bwd pass) -- only for a loss without batch-level terms (x_entropy_coef == 0)
+void launch_loss_fwd_seg(const LossArgs& a, const SegTab& st, bool with_bwd, hipStream_t stream);
+// one workgroup per segment: its block partials -> stats_base + 32 k (phase bit 0), derived terms + record log_base + 8 k (bit 1).
+// fs_parts (from launch_fs_metric_seg, or null): the segment's feature-sparsity metric is finished here and left in fs_out[k]
+void launch_loss_finalize_seg(const LossArgs& a, const SegTab& st, int phase, float* stats_base, const double* fs_parts, int fs_d, float* fs_out,
+                              float* log_base, hipStream_t stream);
+// colmax_scratch: 512 x d floats; fs_parts: n_seg x 8 fp64 column-block sums of tanh(100 max_b relu(h))
+void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, double* fs_parts, hipStream_t stream);
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st);
 
 void launch_gae(const float* rew, const float* done, const float* value, float* adv, float* ret, int T, int E,

@@ -101,6 +101,7 @@ struct mi_ctx {
     uint8_t* stage_frames; float* stage_obs;
     int32_t* d_idx;
     float *loss_partial, *loss_stats, *loss_log; int log_count, log_cap;
+    double* fs_parts;                                     // [MI_MAX_SEG][8] column-block sums of the feature-sparsity metric
     float *stats_ring, *fs_ring; LossArgs ring_args;      // multirank mode 2: per-minibatch raw stats [log_cap][32] (+ rank-local fs), finalised after ONE all-reduce
     double* sumsq; float* gnorm;
     float* d_u; float* d_lp;
@@ -325,7 +326,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(dalloc(&c->loss_stats, 64));
     c->log_cap = 4096; c->log_count = 0;
     HIPC(dalloc(&c->loss_log, (size_t)c->log_cap * 8));
-    HIPC(dalloc(&c->stats_ring, (size_t)c->log_cap * 32)); HIPC(dalloc(&c->fs_ring, (size_t)c->log_cap));
+    HIPC(dalloc(&c->stats_ring, (size_t)c->log_cap * 32)); HIPC(dalloc(&c->fs_ring, (size_t)c->log_cap)); HIPC(dalloc(&c->fs_parts, (size_t)MI_MAX_SEG * 8));
     HIPC(dalloc(&c->sumsq, 2 + 128)); HIPC(dalloc(&c->gnorm, 2)); sumsq_set_workspace(c->sumsq + 2);
     HIPC(dalloc(&c->d_u, (size_t)E));
     HIPC(dalloc(&c->d_pack, (size_t)3 * E)); HIPC(dalloc(&c->d_rd, (size_t)2 * E));
@@ -384,7 +385,7 @@ int mi_destroy(mi_ctx* c) {
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
     if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc);
-    hipFree(c->stats_ring); hipFree(c->fs_ring); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
+    hipFree(c->stats_ring); hipFree(c->fs_ring); hipFree(c->fs_parts); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
@@ -1124,41 +1125,32 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
         // deferred statistics: nothing in the backward pass needs the cross-rank sums when x_entropy_coef == 0 and fs_coef == 0, so this
         // rank's partial sums go to ring slot log_count and are summed over the ranks ONCE per optimize() (mi_loss_log_finalize)
         ARG(!batch_terms, "multirank mode 2 needs x_entropy_coef == 0 and fs_coef == 0 (use mode 1)");
-    if (n_seg > 1) {
-        // loss terms + logged statistics of all segments with one launch each (modes 0 and 2 only): the rank-local sums land in the
-        // statistics ring (mode 0 derives the records right away, mode 2 after the cross-rank sum in mi_loss_log_finalize)
+    if (c->multirank != 1) {
+        // modes 0 and 2: loss terms + logged statistics of all segments with one launch each.  The rank-local sums land in the
+        // statistics ring (mode 0 derives the records right away, mode 2 after the cross-rank sum in mi_loss_log_finalize); without
+        // batch-level terms the sample gradients dY come out of the same pass.
         SegTab st{};
         st.n_seg = n_seg;
         for (int k = 0; k < n_seg; ++k) st.start[k + 1] = st.start[k] + seg_n[k];
         float* ring = c->stats_ring + (size_t)c->log_count * 32;
         float* fsr = c->fs_ring + c->log_count;
-        if (impala) launch_fs_metric_seg(c->blk[2].P2, c->bf, st, 2048, c->fs_scratch, fsr, c->stream);
-        launch_loss_fwd_seg(a, st, c->stream);
-        launch_loss_finalize_seg(a, st, c->multirank == 2 ? 1 : 3, ring, impala ? fsr : nullptr,
+        a.stats = ring;                                  // (x-entropy gradient, mode 0, n_seg == 1: the batch-mean action distribution)
+        if (impala) launch_fs_metric_seg(c->blk[2].P2, c->bf, st, 2048, c->fs_scratch, c->fs_parts, c->stream);
+        launch_loss_fwd_seg(a, st, !batch_terms, c->stream);
+        launch_loss_finalize_seg(a, st, c->multirank == 2 ? 1 : 3, ring, impala ? c->fs_parts : nullptr, 2048, fsr,
                                  c->multirank == 2 ? nullptr : c->loss_log + (size_t)c->log_count * 8, c->stream);
         c->ring_args = a;
         c->log_count += n_seg;
-    } else {
-        if (impala) launch_fs_metric(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_val, c->stream);
-        launch_loss_fwd(a, c->stream);
-        if (c->multirank == 2) {
-            LossArgs g = a; g.stats = c->stats_ring + (size_t)c->log_count * 32;
-            launch_loss_finalize(g, loss_blocks(n), 1, nullptr, nullptr, c->stream);
-            if (impala) HIPC(hipMemcpyAsync(c->fs_ring + c->log_count, c->fs_val, 4, hipMemcpyDeviceToDevice, c->stream));
-            c->ring_args = a;
-            c->log_count++;
-        } else if (c->multirank == 1) {
-            launch_loss_finalize(a, loss_blocks(n), 1, nullptr, nullptr, c->stream);
-            c->pending = a; c->pending_n = n;
-            HIPC(hipGetLastError());
-            return 0;                                   // host all-reduces loss_stats, then mi_minibatch_finish
-        } else {
-            launch_loss_finalize(a, loss_blocks(n), 3, impala ? c->fs_val : nullptr, c->loss_log + (size_t)c->log_count * 8, c->stream);
-            c->log_count++;
-        }
+        if (batch_terms) launch_loss_bwd(a, c->stream);
+        net_backward(c, src, n);
+        HIPC(hipGetLastError());
+        return 0;
     }
-    launch_loss_bwd(a, c->stream);
-    net_backward(c, src, n);
+    // mode 1: the cross-rank sum of the statistics comes between the loss forward and backward (mi_minibatch_finish)
+    if (impala) launch_fs_metric(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_val, c->stream);
+    launch_loss_fwd(a, c->stream);
+    launch_loss_finalize(a, loss_blocks(n), 1, nullptr, nullptr, c->stream);
+    c->pending = a; c->pending_n = n;
     HIPC(hipGetLastError());
     return 0;
 }

@@ -496,9 +496,44 @@ __device__ __forceinline__ void sample_terms(const LossArgs& a, int s, SampleTer
 
 int loss_blocks(int n) { return (n + 255) / 256; }
 
-// one 256-sample block of the loss: sums over the samples s < s_end of this block -> partial row `row`
+__device__ __forceinline__ void loss_bwd_sample(const LossArgs& a, int s, const SampleTerms& t) {
+    const float ib = a.inv_n_global;
+    // d pi_loss / d logp_act  (torch.min routes to surr1 on <=; a tie is the unclipped regime where both
+    // branches carry adv/2 each; clamp passes gradient inside [1-eps, 1+eps])
+    const float g_lp = -ib * ((t.surr1 <= t.surr2) ? t.adv : 0.f) * t.ratio;
+    const float cH = (-a.hp.entropy_coef * a.hp.entropy_mult + a.hp.x_entropy_coef) * ib;
+    float plq = 0.f;
+    float lq[MAXA];
+    const bool xe = a.hp.x_entropy_coef != 0.f;
+    if (xe) for (int k = 0; k < a.A; ++k) { lq[k] = logf(a.stats[8 + k]); plq += t.p[k] * lq[k]; }
+    float* d = a.dY + (long long)s * (a.A + 1);
+    for (int k = 0; k < a.A; ++k) {
+        float gk = g_lp * ((k == t.act ? 1.f : 0.f) - t.p[k]);
+        gk += cH * (-t.p[k] * (t.lp[k] + t.H));
+        if (xe) gk += a.hp.x_entropy_coef * ib * t.p[k] * (lq[k] - plq);
+        d[k] = gk;
+    }
+    const float dvl = t.v - t.oldv;
+    const float inr = (dvl >= -a.hp.eps_clip && dvl <= a.hp.eps_clip) ? 1.f : 0.f;
+    float gv;
+    if (t.vs1 > t.vs2) gv = 2.f * (t.v - t.ret);
+    else if (t.vs2 > t.vs1) gv = 2.f * (t.vclip - t.ret) * inr;
+    else gv = (t.v - t.ret) + (t.vclip - t.ret) * inr;
+    d[a.A] = a.hp.value_coef * 0.5f * ib * gv;
+}
+__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n) return;
+    SampleTerms t;
+    sample_terms(a, s, t);
+    loss_bwd_sample(a, s, t);
+}
+// one 256-sample block of the loss: sums over the samples s < s_end of this block -> partial row `row` (per value: wave sums,
+// then the four waves in order -- the sums of block_sum256 with one barrier instead of two per value).  BWD: the loss has no
+// batch-level term (x_entropy_coef == 0), so the gradient of the sample goes out in the same pass.
+template <bool BWD>
 __device__ __forceinline__ void loss_fwd_block(const LossArgs& a, int s, int s_end, int row) {
-    __shared__ float sb[4];
+    __shared__ float sw[4][8 + MAXA];
     SampleTerms t;
     float pi = 0.f, vm = 0.f, H = 0.f;
     float pa[MAXA];
@@ -509,15 +544,19 @@ __device__ __forceinline__ void loss_fwd_block(const LossArgs& a, int s, int s_e
         vm = fmaxf(t.vs1, t.vs2);
         H = t.H;
         for (int k = 0; k < a.A; ++k) pa[k] = t.p[k];
+        if (BWD) loss_bwd_sample(a, s, t);
     }
-    float* out = a.partial + (long long)row * (8 + a.A);
-    float r = block_sum256(pi, sb); if (threadIdx.x == 0) out[0] = r;
-    r = block_sum256(vm, sb);       if (threadIdx.x == 0) out[1] = r;
-    r = block_sum256(H, sb);        if (threadIdx.x == 0) out[2] = r;
-    for (int k = 0; k < a.A; ++k) { r = block_sum256(pa[k], sb); if (threadIdx.x == 0) out[8 + k] = r; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float r = wave_sum(pi); if (lane == 0) sw[w][0] = r;
+    r = wave_sum(vm);       if (lane == 0) sw[w][1] = r;
+    r = wave_sum(H);        if (lane == 0) sw[w][2] = r;
+    for (int k = 0; k < a.A; ++k) { r = wave_sum(pa[k]); if (lane == 0) sw[w][8 + k] = r; }
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k < 3 || (k >= 8 && k < 8 + a.A)) a.partial[(long long)row * (8 + a.A) + k] = sw[0][k] + sw[1][k] + sw[2][k] + sw[3][k];
 }
 __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a) {
-    loss_fwd_block(a, blockIdx.x * 256 + threadIdx.x, a.n, blockIdx.x);
+    loss_fwd_block<false>(a, blockIdx.x * 256 + threadIdx.x, a.n, blockIdx.x);
 }
 // segment k owns ceil(len_k / 256) consecutive blocks (no block straddles two minibatches)
 __device__ __forceinline__ void seg_of_block(const SegTab& st, int b, int& k, int& first) {
@@ -528,20 +567,22 @@ __device__ __forceinline__ void seg_of_block(const SegTab& st, int b, int& k, in
         first += nb;
     }
 }
+template <bool BWD>
 __global__ __launch_bounds__(256) void loss_fwd_seg_kernel(LossArgs a, SegTab st) {
     int k, first;
     seg_of_block(st, blockIdx.x, k, first);
-    loss_fwd_block(a, st.start[k] + (blockIdx.x - first) * 256 + threadIdx.x, st.start[k + 1], blockIdx.x);
+    loss_fwd_block<BWD>(a, st.start[k] + (blockIdx.x - first) * 256 + threadIdx.x, st.start[k + 1], blockIdx.x);
 }
 int loss_blocks_seg(const SegTab& st) {
     int nb = 0;
     for (int k = 0; k < st.n_seg; ++k) nb += (st.start[k + 1] - st.start[k] + 255) / 256;
     return nb;
 }
-void launch_loss_fwd_seg(const LossArgs& a, const SegTab& st, hipStream_t stream) {
+void launch_loss_fwd_seg(const LossArgs& a, const SegTab& st, bool with_bwd, hipStream_t stream) {
     const int nb = loss_blocks_seg(st);
     if (nb <= 0) return;
-    hipLaunchKernelGGL(loss_fwd_seg_kernel, dim3(nb), dim3(256), 0, stream, a, st);
+    if (with_bwd) hipLaunchKernelGGL(loss_fwd_seg_kernel<true>, dim3(nb), dim3(256), 0, stream, a, st);
+    else hipLaunchKernelGGL(loss_fwd_seg_kernel<false>, dim3(nb), dim3(256), 0, stream, a, st);
 }
 void launch_loss_fwd(const LossArgs& a, hipStream_t st) {
     if (a.n <= 0) return;
@@ -580,50 +621,28 @@ __device__ __forceinline__ void loss_finalize_body(const LossArgs& a, int nblk, 
 __global__ void loss_finalize_kernel(LossArgs a, int nblk, int phase, const float* fs_ptr, float* log_slot) {
     loss_finalize_body(a, nblk, phase, fs_ptr, log_slot);
 }
-__global__ void loss_finalize_seg_kernel(LossArgs a, SegTab st, int phase, float* stats_base, const float* fs_base, float* log_base) {
+__global__ void loss_finalize_seg_kernel(LossArgs a, SegTab st, int phase, float* stats_base, const double* fs_parts, int fs_d, float* fs_out,
+                                         float* log_base) {
     const int k = blockIdx.x;
     int first = 0;
     for (int j = 0; j < k; ++j) first += (st.start[j + 1] - st.start[j] + 255) / 256;
     a.partial += (long long)first * (8 + a.A);
     a.stats = stats_base + 32 * k;
-    loss_finalize_body(a, (st.start[k + 1] - st.start[k] + 255) / 256, phase, fs_base ? fs_base + k : nullptr, log_base ? log_base + 8 * k : nullptr);
+    if (fs_parts && threadIdx.x == 0) {                 // second half of the feature-sparsity metric: mean over the d columns
+        double tot = 0.0;
+        for (int j = 0; j < FS_PARTS; ++j) tot += fs_parts[k * FS_PARTS + j];
+        fs_out[k] = (float)(tot / fs_d);
+    }
+    loss_finalize_body(a, (st.start[k + 1] - st.start[k] + 255) / 256, phase, fs_parts ? fs_out + k : nullptr, log_base ? log_base + 8 * k : nullptr);
 }
-void launch_loss_finalize_seg(const LossArgs& a, const SegTab& st, int phase, float* stats_base, const float* fs_base, float* log_base, hipStream_t stream) {
-    hipLaunchKernelGGL(loss_finalize_seg_kernel, dim3(st.n_seg), dim3(64), 0, stream, a, st, phase, stats_base, fs_base, log_base);
+void launch_loss_finalize_seg(const LossArgs& a, const SegTab& st, int phase, float* stats_base, const double* fs_parts, int fs_d, float* fs_out,
+                              float* log_base, hipStream_t stream) {
+    hipLaunchKernelGGL(loss_finalize_seg_kernel, dim3(st.n_seg), dim3(64), 0, stream, a, st, phase, stats_base, fs_parts, fs_d, fs_out, log_base);
 }
 void launch_loss_finalize(const LossArgs& a, int nblk, int phase, const float* fs_ptr, float* log_slot, hipStream_t st) {
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a, nblk, phase, fs_ptr, log_slot);
 }
 
-__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= a.n) return;
-    SampleTerms t;
-    sample_terms(a, s, t);
-    const float ib = a.inv_n_global;
-    // d pi_loss / d logp_act  (torch.min routes to surr1 on <=; a tie is the unclipped regime where both
-    // branches carry adv/2 each; clamp passes gradient inside [1-eps, 1+eps])
-    const float g_lp = -ib * ((t.surr1 <= t.surr2) ? t.adv : 0.f) * t.ratio;
-    const float cH = (-a.hp.entropy_coef * a.hp.entropy_mult + a.hp.x_entropy_coef) * ib;
-    float plq = 0.f;
-    float lq[MAXA];
-    const bool xe = a.hp.x_entropy_coef != 0.f;
-    if (xe) for (int k = 0; k < a.A; ++k) { lq[k] = logf(a.stats[8 + k]); plq += t.p[k] * lq[k]; }
-    float* d = a.dY + (long long)s * (a.A + 1);
-    for (int k = 0; k < a.A; ++k) {
-        float gk = g_lp * ((k == t.act ? 1.f : 0.f) - t.p[k]);
-        gk += cH * (-t.p[k] * (t.lp[k] + t.H));
-        if (xe) gk += a.hp.x_entropy_coef * ib * t.p[k] * (lq[k] - plq);
-        d[k] = gk;
-    }
-    const float dvl = t.v - t.oldv;
-    const float inr = (dvl >= -a.hp.eps_clip && dvl <= a.hp.eps_clip) ? 1.f : 0.f;
-    float gv;
-    if (t.vs1 > t.vs2) gv = 2.f * (t.v - t.ret);
-    else if (t.vs2 > t.vs1) gv = 2.f * (t.vclip - t.ret) * inr;
-    else gv = (t.v - t.ret) + (t.vclip - t.ret) * inr;
-    d[a.A] = a.hp.value_coef * 0.5f * ib * gv;
-}
 void launch_loss_bwd(const LossArgs& a, hipStream_t st) {
     if (a.n <= 0) return;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(loss_blocks(a.n)), dim3(256), 0, st, a);
@@ -669,48 +688,57 @@ __global__ __launch_bounds__(1024) void fs_finalize_kernel(const float* part, in
     __syncthreads();
     if (threadIdx.x == 0) { double tot = 0.0; for (int k = 0; k < 16; ++k) tot += sb[k]; fs_out[0] = (float)(tot / d); }
 }
-__global__ __launch_bounds__(256) void colmax_partial_seg_kernel(const void* x, int bf16, SegTab st, int d, float* part) {
+// segment-aware two-stage version (mi_minibatch_multi and the single-minibatch path of modes 0 / 2): G row groups per segment with
+// G x n_seg ~ 512 workgroups (all CUs busy, 4 rows in flight per thread), then FS_PARTS column blocks per segment whose fp64
+// partial sums the loss finalisation adds up.
+__device__ __forceinline__ void fs_row_max(const void* x, int bf16, long long o, float (&m)[8]) {
+    if (bf16) {
+        const uint4 u = *(const uint4*)((const unsigned short*)x + o);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (q & 1) ? __uint_as_float(w[q >> 1] & 0xffff0000u) : __uint_as_float(w[q >> 1] << 16));
+    } else {
+        const f32x4 lo = *(const f32x4*)((const float*)x + o), hi = *(const f32x4*)((const float*)x + o + 4);
+        m[0] = fmaxf(m[0], lo.x); m[1] = fmaxf(m[1], lo.y); m[2] = fmaxf(m[2], lo.z); m[3] = fmaxf(m[3], lo.w);
+        m[4] = fmaxf(m[4], hi.x); m[5] = fmaxf(m[5], hi.y); m[6] = fmaxf(m[6], hi.z); m[7] = fmaxf(m[7], hi.w);
+    }
+}
+__global__ __launch_bounds__(256) void colmax_partial_seg_kernel(const void* x, int bf16, SegTab st, int d, int G, float* part) {
     const int k = blockIdx.y, r0 = st.start[k], r1 = st.start[k + 1];
     for (int j = threadIdx.x * 8; j < d; j += 256 * 8) {
         float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int b = r0 + blockIdx.x; b < r1; b += FS_GROUPS) {
-            const long long o = (long long)b * d + j;
-            if (bf16) {
-                const uint4 u = *(const uint4*)((const unsigned short*)x + o);
-                const unsigned w[4] = {u.x, u.y, u.z, u.w};
+        int b = r0 + blockIdx.x;
+        for (; b + 3 * G < r1; b += 4 * G) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (q & 1) ? __uint_as_float(w[q >> 1] & 0xffff0000u) : __uint_as_float(w[q >> 1] << 16));
-            } else {
-                const f32x4 lo = *(const f32x4*)((const float*)x + o), hi = *(const f32x4*)((const float*)x + o + 4);
-                m[0] = fmaxf(m[0], lo.x); m[1] = fmaxf(m[1], lo.y); m[2] = fmaxf(m[2], lo.z); m[3] = fmaxf(m[3], lo.w);
-                m[4] = fmaxf(m[4], hi.x); m[5] = fmaxf(m[5], hi.y); m[6] = fmaxf(m[6], hi.z); m[7] = fmaxf(m[7], hi.w);
-            }
+            for (int u = 0; u < 4; ++u) fs_row_max(x, bf16, (long long)(b + u * G) * d + j, m);
         }
-        float* p = part + ((long long)k * FS_GROUPS + blockIdx.x) * d + j;
+        for (; b < r1; b += G) fs_row_max(x, bf16, (long long)b * d + j, m);
+        float* p = part + ((long long)k * G + blockIdx.x) * d + j;
         *(f32x4*)p = (f32x4){m[0], m[1], m[2], m[3]};
         *(f32x4*)(p + 4) = (f32x4){m[4], m[5], m[6], m[7]};
     }
 }
-__global__ __launch_bounds__(1024) void fs_finalize_seg_kernel(const float* part, int groups, int d, float* fs_out) {
-    __shared__ double sb[16];
-    part += (long long)blockIdx.x * groups * d;
+__global__ __launch_bounds__(256) void fs_parts_seg_kernel(const float* part, int G, int d, double* fs_parts) {
+    __shared__ double sb[4];
+    const int k = blockIdx.y, cols = d / FS_PARTS;
+    part += (long long)k * G * d;
     double s = 0.0;
-    for (int j = threadIdx.x; j < d; j += 1024) {
+    for (int j = blockIdx.x * cols + threadIdx.x; j < (blockIdx.x + 1) * cols; j += 256) {
         float m = 0.f;
 #pragma unroll 16
-        for (int g = 0; g < groups; ++g) m = fmaxf(m, part[(long long)g * d + j]);
+        for (int g = 0; g < G; ++g) m = fmaxf(m, part[(long long)g * d + j]);
         s += (double)tanhf(fabsf(m * 100.f));
     }
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sb[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { double tot = 0.0; for (int k = 0; k < 16; ++k) tot += sb[k]; fs_out[blockIdx.x] = (float)(tot / d); }
+    const double t = block_sum256(s, sb);
+    if (threadIdx.x == 0) fs_parts[k * FS_PARTS + blockIdx.x] = t;
 }
-void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, float* fs_out, hipStream_t stream) {
+int fs_groups_per_segment(int n_seg) { int g = 512 / (n_seg < 1 ? 1 : n_seg); int p = 32; while (p * 2 <= g) p *= 2; return p; }
+void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, double* fs_parts, hipStream_t stream) {
     if (st.n_seg <= 0) return;
-    if (d % 8) abort();
-    hipLaunchKernelGGL(colmax_partial_seg_kernel, dim3(FS_GROUPS, st.n_seg), dim3(256), 0, stream, flat_pre, bf16, st, d, colmax_scratch);
-    hipLaunchKernelGGL(fs_finalize_seg_kernel, dim3(st.n_seg), dim3(1024), 0, stream, (const float*)colmax_scratch, FS_GROUPS, d, fs_out);
+    if (d % (8 * FS_PARTS)) abort();
+    const int G = fs_groups_per_segment(st.n_seg);
+    hipLaunchKernelGGL(colmax_partial_seg_kernel, dim3(G, st.n_seg), dim3(256), 0, stream, flat_pre, bf16, st, d, G, colmax_scratch);
+    hipLaunchKernelGGL(fs_parts_seg_kernel, dim3(FS_PARTS, st.n_seg), dim3(256), 0, stream, (const float*)colmax_scratch, G, d, fs_parts);
 }
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st) {
     if (n <= 0) return;
