@@ -88,19 +88,34 @@ def initialize_model(device, env, hp):
 
 
 def train_ppo(args):
-    set_global_seeds(args.seed)
     hp = get_hyperparams(args.param_name)
     for k in ("n_envs", "n_steps", "n_minibatch", "mini_batch_size", "learning_rate", "entropy_coef", "x_entropy_coef", "precision"):
         if getattr(args, k, None) is not None:
             hp[k] = getattr(args, k)
     if hp.get("algo", "ppo") != "ppo":
         raise NotImplementedError("only algo: ppo is accelerated")
+    # (new) one process per GPU under `python -m torch.distributed.run --nproc-per-node R train.py ...`: every rank owns
+    # n_envs / R environments (its own env instances, seeded per rank) and the agent shards the update
+    world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
+    if world > 1:
+        args.gpu_device = int(os.environ.get("LOCAL_RANK", 0))
+        torch.cuda.set_device(args.gpu_device)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", args.gpu_device))
+        if hp.get("n_envs", 256) % world:
+            raise ValueError(f"n_envs={hp.get('n_envs', 256)} is not divisible by WORLD_SIZE={world}")
+        hp["n_envs"] = hp.get("n_envs", 256) // world
+        seed_t = torch.tensor([args.seed], dtype=torch.int64, device=torch.device("cuda", args.gpu_device))
+        torch.distributed.broadcast(seed_t, 0)              # same initial weights and minibatch permutations on every rank
+        args.seed = int(seed_t.item())
+    set_global_seeds(args.seed)
     device = torch.device("cuda", args.gpu_device)
     n_envs, n_steps = hp.get("n_envs", 256), hp.get("n_steps", 256)
     A = 15 if hp.get("architecture", "impala") == "impala" else 2
-    env = make_env(args.env_name, n_envs, args.seed, A, args, hp)
-    env_valid = make_env(args.env_name, n_envs, args.seed + 1, A, args, hp, is_valid=True) if args.use_valid_env else None
-    logdir = os.path.join('logs', 'train', args.env_name, args.exp_name, time.strftime("%Y-%m-%d__%H-%M-%S") + f'__seed_{args.seed}')
+    env = make_env(args.env_name, n_envs, args.seed + 2 * rank, A, args, hp)
+    env_valid = make_env(args.env_name, n_envs, args.seed + 2 * rank + 1, A, args, hp, is_valid=True) if args.use_valid_env else None
+    logdir = os.path.join('logs', 'train', args.env_name, args.exp_name, time.strftime("%Y-%m-%d__%H-%M-%S") + f'__seed_{args.seed}'
+                          + (f'__rank_{rank}' if world > 1 else ''))
     os.makedirs(logdir, exist_ok=True)
     np.save(os.path.join(logdir, "hyperparameters.npy"), hp)
     model, obs_shape, policy = initialize_model(device, env, hp)
@@ -109,7 +124,7 @@ def train_ppo(args):
     storage = Storage(obs_shape, model.output_dim, n_steps, n_envs, device)
     storage_valid = Storage(obs_shape, model.output_dim, n_steps, n_envs, device) if args.use_valid_env else None
     agent = PPO(env, policy, logger, storage, device, args.num_checkpoints, env_valid=env_valid, storage_valid=storage_valid,
-                seed=args.seed, **hp)
+                seed=args.seed + rank, **hp)
     if args.model_file is not None:
         ck = torch.load(args.model_file, map_location="cpu", weights_only=True)
         agent.policy.load_state_dict(ck["model_state_dict"])
