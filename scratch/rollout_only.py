@@ -12,8 +12,10 @@ for t in range(T + 1):
     stage[...] = rng.integers(0, 256, size=stage.shape, dtype=np.uint8)
     eng.put_obs(t, stage); eng.sync()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+USE_RD = len(sys.argv) > 2 and sys.argv[2] == 'rd'
+RD = (np.zeros(E, np.float32), np.zeros(E, np.float32))
 for it in range(n):
     t0 = time.perf_counter()
     for t in range(T + 1):
-        eng.rollout_step(t, None, None, seed=it)
+        eng.rollout_step(t, (RD[0] if t and USE_RD else None), (RD[1] if t and USE_RD else None), seed=it)
     print("rollout ms", (time.perf_counter() - t0) * 1e3, flush=True)
