@@ -181,6 +181,7 @@ void launch_loss_fwd_seg(const LossArgs& a, const SegTab& st, bool with_bwd, hip
 // fs_parts (from launch_fs_metric_seg, or null): the segment's feature-sparsity metric is finished here and left in fs_out[k]
 void launch_loss_finalize_seg(const LossArgs& a, const SegTab& st, int phase, float* stats_base, const double* fs_parts, int fs_d, float* fs_out,
                               float* log_base, hipStream_t stream);
+void launch_loss_finalize_records(const LossArgs& a, int n_rec, float* stats_base, const float* fs_base, float* log_base, hipStream_t stream);
 // colmax_scratch: 512 x d floats; fs_parts: n_seg x 8 fp64 column-block sums of tanh(100 max_b relu(h))
 void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, double* fs_parts, hipStream_t stream);
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st);

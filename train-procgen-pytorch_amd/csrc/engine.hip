@@ -1168,10 +1168,7 @@ int mi_set_multirank(mi_ctx* c, int32_t enabled) { ARG(c, "null"); ARG(enabled >
 int mi_loss_log_finalize(mi_ctx* c) {
     ARG(c, "null"); ARG(c->multirank == 2, "only in multirank mode 2");
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
-    for (int k = 0; k < c->log_count; ++k) {
-        LossArgs r = c->ring_args; r.stats = c->stats_ring + (size_t)k * 32;
-        launch_loss_finalize(r, 0, 2, impala ? c->fs_ring + k : nullptr, c->loss_log + (size_t)k * 8, c->stream);
-    }
+    launch_loss_finalize_records(c->ring_args, c->log_count, c->stats_ring, impala ? c->fs_ring : nullptr, c->loss_log, c->stream);
     HIPC(hipGetLastError());
     return 0;
 }

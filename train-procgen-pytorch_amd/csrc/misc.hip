@@ -635,6 +635,16 @@ __global__ void loss_finalize_seg_kernel(LossArgs a, SegTab st, int phase, float
     }
     loss_finalize_body(a, (st.start[k + 1] - st.start[k] + 255) / 256, phase, fs_parts ? fs_out + k : nullptr, log_base ? log_base + 8 * k : nullptr);
 }
+// phase 2 of n_rec records at once (after the cross-rank sum of the statistics ring): record k from stats_base + 32 k, fs_base[k]
+__global__ void loss_finalize_records_kernel(LossArgs a, float* stats_base, const float* fs_base, float* log_base) {
+    const int k = blockIdx.x;
+    a.stats = stats_base + 32 * k;
+    loss_finalize_body(a, 0, 2, fs_base ? fs_base + k : nullptr, log_base + 8 * k);
+}
+void launch_loss_finalize_records(const LossArgs& a, int n_rec, float* stats_base, const float* fs_base, float* log_base, hipStream_t stream) {
+    if (n_rec <= 0) return;
+    hipLaunchKernelGGL(loss_finalize_records_kernel, dim3(n_rec), dim3(64), 0, stream, a, stats_base, fs_base, log_base);
+}
 void launch_loss_finalize_seg(const LossArgs& a, const SegTab& st, int phase, float* stats_base, const double* fs_parts, int fs_d, float* fs_out,
                               float* log_base, hipStream_t stream) {
     hipLaunchKernelGGL(loss_finalize_seg_kernel, dim3(st.n_seg), dim3(64), 0, stream, a, st, phase, stats_base, fs_parts, fs_d, fs_out, log_base);
