@@ -896,12 +896,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_bf16_kernel(ConvArgs a, const u
 // (one halo row recomputed), which only ever exist in LDS -- the 64x64x16 conv output, the largest tensor of the
 // network, is neither written nor re-read (the backward pass needs the pooled arg-max, not the conv output).
 using C1P = C1T<9>;
+#ifndef C1P_SC
+#define C1P_SC 24         // conv-output tile pixel stride in LDS (bf16 elements)
+#endif
 __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, const unsigned short* lut16, unsigned short* p_out, uint8_t* p_arg) {
     __shared__ __attribute__((aligned(16))) unsigned short s_in[C1P::NPIX * 4];
     __shared__ __attribute__((aligned(16))) unsigned short s_w[16 * C1_WS];
     // conv-output tile as ORDER-PRESERVING KEYS (common.h), [9 rows][1 pad + 64 px][16 ch]: the pad cell is column -1 of its row
-    // (minimal keys, written once).  (A 1.5-pixel stride makes the pooling reads conflict-free but measured slower: 11.3 vs 8.5 ms.)
-    __shared__ __attribute__((aligned(16))) unsigned short s_c[9 * 65 * 16];
+    // (minimal keys, written once).  Pixel stride 24 elements = 1.5 pixels: the pooling reads (lanes two pixels apart) then hit every
+    // bank once -- 5.9 vs 6.1 ms per iteration with the key-based pooling (with the float compare chain it had measured slower).
+    __shared__ __attribute__((aligned(16))) unsigned short s_c[9 * 65 * C1P_SC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
 #ifdef WG_TIMING
     long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
         s_w[e] = f2bf((k < 36 && ci < 3) ? a.w[(j * 9 + tap) * 3 + ci] : 0.f);
     }
     for (int e = tid; e < C1P::NPIX * 4; e += 256) s_in[e] = 0;
-    if (tid < 9 * 8) ((unsigned*)s_c)[(tid >> 3) * 65 * 8 + (tid & 7)] = MI_KEY_MIN2;
+    if (tid < 9 * 8) ((unsigned*)s_c)[(tid >> 3) * 65 * (C1P_SC / 2) + (tid & 7)] = MI_KEY_MIN2;
     float bias4[4];                                        // output channels 4*kq .. 4*kq+3 (the MFMA's row quad)
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias4[r] = a.bias ? a.bias[kq * 4 + r] : 0.f;
@@ -959,7 +963,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
                 const bool dead = cy0 < 0 && t < 4;
                 const unsigned k0 = mi_bf16x2_to_keys(mi_pk_bf16(acc[m][0] + bias4[0], acc[m][1] + bias4[1]));
                 const unsigned k1 = mi_bf16x2_to_keys(mi_pk_bf16(acc[m][2] + bias4[2], acc[m][3] + bias4[3]));
-                *(uint2*)(s_c + (t * 16 + i + (t >> 2) + 1) * 16 + kq * 4) = (uint2){dead ? MI_KEY_MIN2 : k0, dead ? MI_KEY_MIN2 : k1};
+                *(uint2*)(s_c + (t * 16 + i + (t >> 2) + 1) * C1P_SC + kq * 4) = (uint2){dead ? MI_KEY_MIN2 : k0, dead ? MI_KEY_MIN2 : k1};
             }
         }
         TCK(5);
@@ -972,7 +976,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
-                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * 65 + 2 * ox + kx) * 16 + c8 * 8);
+                    u[ky * 3 + kx] = *(const uint4*)(s_c + ((2 * oyl + ky) * 65 + 2 * ox + kx) * C1P_SC + c8 * 8);
             const size_t o = ((((size_t)img * 32 + oy0 + oyl) * 32 + ox) * 2 + c8) * 8;
             uint4 pk;
             uint2 ar;
