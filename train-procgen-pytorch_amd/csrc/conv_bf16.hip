@@ -942,7 +942,8 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
         // LDS store per tile.  All 9 tiles accumulate into their own registers first (18 independent MFMAs back to back), the
         // epilogues follow: with a single accumulator every tile waited for the previous tile's read-out.
 #ifndef C1P_GROUP
-#define C1P_GROUP 1          // tiles accumulated together before their epilogues (scratch/kbench.hip sweep: 1 -> 328 us, 3 -> 403, 9 -> 383 per 8192 frames)
+#define C1P_GROUP 3          // tiles accumulated together before their epilogues (scratch/kbench.hip, per 8192 frames: 1 -> 258-262 us, 3 -> 252-259,
+                             // 9 -> 279-282 with the key-based pooling; with the float compare chain it was 328 / 403 / 383)
 #endif
 #pragma unroll
         for (int g0 = 0; g0 < 9; g0 += C1P_GROUP) {
