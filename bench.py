@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--profile-period", type=int, default=8, help="bracket every P-th minibatch update with HIP events (1 = all)")
     ap.add_argument("--rank-share", type=int, default=1, help="diagnostic: on ONE GPU, run the launch sizes a rank of an R-GPU job sees "
                     "(minibatches of mini_batch_size/R, R-fold gradient accumulation, no collectives)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="diagnostic: run the N-rank code path (sharding, merged accumulation, "
+                    "gradient / statistics all-reduce, barriers) with every rank on GPU 0 and the gloo backend; the number it prints is not a result")
     ap.add_argument("--h2d", action="store_true", help="also upload the E frames of every rollout step from pinned host memory")
     args = ap.parse_args()
 
@@ -173,12 +175,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from agents.ppo import PPO
     from common.model import ImpalaModel
@@ -283,7 +290,7 @@ def main():
                         sampled="HIP events bracket every %d-th minibatch update (same launch sizes in all of them)" % max(1, args.profile_period))
         out = {"metric": "env steps/sec (whole node), coinrun hard-500 IMPALA-CNN PPO", "value": value, "unit": "env steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if args.precision == "bf16" else "f32"), "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if args.precision == "bf16" else "f32"), "data": "synthetic" + (" -- REHEARSAL: every rank on GPU 0, gloo; not a result" if args.rehearse_on_one_gpu else ""),
                "config": {"workload": f"PPO iteration, {args.param_name}: IMPALA-CNN, T={T}, E={E} envs per GPU, "
                                       f"{hp['epoch']} epochs x {hp['n_minibatch']} minibatches of {agent.mini_batch_size} (global), "
                                       f"A={A}, frames resident in HBM" + (" + per-step H2D" if args.h2d else ""),
