@@ -93,3 +93,87 @@ def test_two_rank_gradients_equal_single_process(tmp_path):
     assert 0 < int(got["n_local"]) < B
     assert abs(float(got["loss"][0]) - L["total"]) < 1e-5
     np.testing.assert_allclose(got["grad"], ref, rtol=1e-4, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ the update schedule (mi355/dist.py::update_plan)
+def _plan_worker(rank, world, port, out, merge, xent):
+    """Plays agents/ppo.py::optimize on CPU: the plan's operations drive real gloo collectives and a recording stand-in for the
+    engine (per-sample 'gradient' = one-hot of the sample index, so the all-reduced sum says which samples were visited)."""
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mi355.dist import Collective, env_range, update_plan
+    coll = Collective()
+    Tn, Eg, Bm, n_mini, epochs = 6, 16, 12, 2, 2                 # N = 96, batch_size = 48, 4 accumulated minibatches per step
+    N = Tn * Eg
+    gas = (N // n_mini) / Bm
+    e0, e1 = env_range(Eg, rank, world)
+    El = e1 - e0
+    max_batch = 30                                                # forces a split inside an accumulation group now and then
+    torch.manual_seed(21)                                         # same permutation stream on every rank
+
+    def chunks():
+        for _ in range(epochs):
+            perm = torch.randperm(N).numpy()
+            for k in range(N // Bm):
+                yield perm[k * Bm:(k + 1) * Bm]
+
+    grads = torch.zeros(N)                                        # 'flat gradient': visit counts of GLOBAL sample ids
+    ring = torch.zeros(64)                                        # per-minibatch statistic: number of samples seen
+    visits_per_step, passes, n_stats, log_n, mb_i = [], [], 0, None, 0
+    for op in update_plan(chunks(), rank, world, Eg, gas, merge, coll.active and xent, max_batch, max_segments=3):
+        if op[0] == "minibatch":
+            _, local, seg_n, n_global = op
+            assert n_global == Bm and sum(seg_n) == len(local) and len(local) <= max(max_batch, Bm) and len(seg_n) <= 3
+            assert merge or len(seg_n) == 1
+            t, e = local // El, local % El                        # local flat index -> global sample id
+            np.add.at(grads.numpy(), t * Eg + e + e0, 1.0)
+            for c in seg_n:
+                ring[mb_i] += c
+                mb_i += 1
+            passes.append(list(seg_n))
+        elif op[0] == "stats":
+            s = torch.tensor([float(passes[-1][0])])
+            coll.allreduce_sum_(s)
+            assert s.item() == Bm                                 # the ranks' shares of ONE minibatch
+            n_stats += 1
+        elif op[0] == "step":
+            coll.allreduce_sum_(grads)
+            visits_per_step.append(grads.clone())
+            grads.zero_()
+        else:
+            log_n = op[1]
+            coll.allreduce_sum_(ring[:log_n])
+    if rank == 0:
+        np.savez(out, visits=torch.stack(visits_per_step).numpy(), ring=ring.numpy(), log_n=log_n, n_stats=n_stats,
+                 n_passes=len(passes), max_seg=max(len(p) for p in passes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_plan(tmp_path, merge, xent, port):
+    out = str(tmp_path / f"plan_{int(merge)}{int(xent)}.npz")
+    mp.spawn(_plan_worker, args=(2, port, out, merge, xent), nprocs=2, join=True)
+    return np.load(out)
+
+
+def test_update_plan_two_ranks_visit_every_sample_once_per_epoch(tmp_path):
+    """The accumulation groups of 4 minibatches (48 samples) between optimizer steps: whatever the schedule (one pass per minibatch,
+    per-minibatch statistics exchange, or merged passes split by max_batch / max_segments), the all-reduced 'gradient' of every step
+    counts each of its 48 samples exactly once, the per-minibatch statistics sum to the global minibatch size, and both ranks issue
+    the same collectives (else gloo would hang / mismatch)."""
+    port = 29700 + os.getpid() % 200
+    base = _run_plan(tmp_path, False, False, port)
+    exch = _run_plan(tmp_path, False, True, port + 1)
+    merged = _run_plan(tmp_path, True, False, port + 2)
+    for r in (base, exch, merged):
+        v = r["visits"]
+        assert v.shape == (4, 96)                                 # 2 epochs x 2 optimizer steps
+        assert set(np.unique(v)) <= {0.0, 1.0} and (v.sum(1) == 48).all()
+        assert (v[0] + v[1] == 1).all() and (v[2] + v[3] == 1).all()      # an epoch = a permutation of all samples
+        assert int(r["log_n"]) == 16 and (r["ring"][:16] == 12).all() and (r["ring"][16:] == 0).all()
+    assert np.array_equal(base["visits"], merged["visits"]) and np.array_equal(base["visits"], exch["visits"])
+    assert int(base["n_passes"]) == 16 and int(base["n_stats"]) == 0 and int(exch["n_stats"]) == 16
+    assert int(merged["n_passes"]) < 16 and 2 <= int(merged["max_seg"]) <= 3

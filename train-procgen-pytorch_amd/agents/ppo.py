@@ -13,7 +13,7 @@ import torch
 
 from common.misc_util import adjust_lr, adjust_lr_grok
 from common.model import as_device_obs
-from mi355.dist import Collective, DevicePointerTensor, shard_indices
+from mi355.dist import Collective, DevicePointerTensor, update_plan
 from mi355.engine import Engine, PTR_GRADS, PTR_LOSS_STATS, PTR_STATS_RING
 from mi355.optim import DeviceAdam
 from .base_agent import BaseAgent
@@ -165,7 +165,6 @@ class PPO(BaseAgent):
         if batch_size < self.mini_batch_size:
             self.mini_batch_size = batch_size
         grad_accumulation_steps = batch_size / self.mini_batch_size
-        cnt = 1
         eng, coll, hp = self.engine, self.coll, self._hparams()
         recurrent = self.policy.is_recurrent()
         # Multi-rank: the backward pass needs a cross-rank statistic (the batch-mean action distribution) only for the x-entropy
@@ -178,45 +177,34 @@ class PPO(BaseAgent):
         # minibatches go through the network in ONE pass (mi_minibatch_multi; losses still taken and logged per minibatch).  On R
         # ranks a share is ~1/R of a minibatch, so this keeps every launch at single-GPU size instead of R-fold smaller.
         merge = self.merge_accumulation and no_batch_terms and grad_accumulation_steps > 1
-        n_mb = 0
         if coll.active:
             eng.set_multirank(2 if deferred else 1)
-        held, held_n, held_global = [], 0, self.mini_batch_size
 
-        def flush():
-            nonlocal held, held_n
-            if held:
-                eng.minibatch_multi(np.concatenate(held), [len(h) for h in held], held_global, hp)
-            held, held_n = [], 0
+        def chunks():
+            for _ in range(self.epoch):
+                yield from self.storage.minibatch_index_stream(self.mini_batch_size, recurrent, self.n_envs_global)
 
-        for _ in range(self.epoch):
-            for chunk in self.storage.minibatch_index_stream(self.mini_batch_size, recurrent, self.n_envs_global):
-                local = shard_indices(chunk, self.n_envs_global, coll.rank, coll.world)
-                n_mb += 1
-                if merge:
-                    if held_n + len(local) > eng.max_batch or len(held) == 16 or (held and len(chunk) != held_global):
-                        flush()
-                    held.append(local)
-                    held_n += len(local)
-                    held_global = len(chunk)
+        for op in update_plan(chunks(), coll.rank, coll.world, self.n_envs_global, grad_accumulation_steps, merge,
+                              coll.active and not deferred, eng.max_batch):
+            if op[0] == "minibatch":
+                _, local, seg_n, n_global = op
+                if len(seg_n) > 1 or merge:
+                    eng.minibatch_multi(local, seg_n, n_global, hp)
                 else:
-                    eng.minibatch(local, len(chunk), hp)
-                    if coll.active and not deferred:
-                        with torch.cuda.stream(self._tstream):
-                            coll.allreduce_sum_(self._stats_t)   # 32 floats: loss sums + mean action probabilities
-                        eng.minibatch_finish()
-                if cnt % grad_accumulation_steps == 0:
-                    flush()
-                    if coll.active:
-                        with torch.cuda.stream(self._tstream):
-                            coll.allreduce_sum_(self._grads_t)   # ONE collective per optimizer step: the flat gradient
-                    self.optimizer.step(self.grad_clip_norm)
-                cnt += 1
-        flush()
-        if deferred:
-            with torch.cuda.stream(self._tstream):
-                coll.allreduce_sum_(self._ring_t[:32 * n_mb])
-            eng.loss_log_finalize()
+                    eng.minibatch(local, n_global, hp)
+            elif op[0] == "stats":
+                with torch.cuda.stream(self._tstream):
+                    coll.allreduce_sum_(self._stats_t)       # 32 floats: loss sums + mean action probabilities
+                eng.minibatch_finish()
+            elif op[0] == "step":
+                if coll.active:
+                    with torch.cuda.stream(self._tstream):
+                        coll.allreduce_sum_(self._grads_t)   # ONE collective per optimizer step: the flat gradient
+                self.optimizer.step(self.grad_clip_norm)
+            elif deferred:                                   # ("log", n): the statistics ring, once per optimize()
+                with torch.cuda.stream(self._tstream):
+                    coll.allreduce_sum_(self._ring_t[:32 * op[1]])
+                eng.loss_log_finalize()
         log = eng.loss_log(reset=True)
         nan = float("nan")
         fs = float(np.mean(log[:, 5])) if self.policy.arch == "impala" else nan

@@ -42,6 +42,58 @@ def merge_adv_stats(stats_list):
     return np.array([n, mean, m2], dtype=np.float64)
 
 
+def update_plan(chunks, rank, world, n_envs_global, grad_accumulation_steps, merge, stats_per_minibatch, max_batch, max_segments=16):
+    """The host schedule of PPO.optimize (agents/ppo.py:155-177) for one rank, as a stream of operations -- pure index logic, no
+    device: agents/ppo.py executes it on the engine, tests/test_dist_gloo.py on two CPU ranks.
+
+    chunks: the global minibatches (flat index arrays, all epochs back to back; every rank sees the same ones).  Yields
+      ("minibatch", local_idx, seg_n, n_global)  one pass over this rank's samples of len(seg_n) global minibatches (1 unless `merge`:
+                                                 accumulated minibatches whose gradients are summed anyway, <= max_batch samples and
+                                                 <= max_segments minibatches per pass, never across an optimizer step)
+      ("stats",)                                 only with stats_per_minibatch (x-entropy term on > 1 rank): all-reduce the loss
+                                                 statistics of the pass just issued, then finish it (backward)
+      ("step",)                                  after every grad_accumulation_steps-th minibatch (the reference's `cnt % steps == 0`
+                                                 with a float): gradient all-reduce + optimizer step
+      ("log", n_minibatches)                     once at the end: reduce / read the per-minibatch records
+    """
+    assert not (merge and stats_per_minibatch)
+    held, held_n, held_global, n_mb, cnt = [], 0, None, 0, 1
+
+    def flush():
+        nonlocal held, held_n
+        if held:
+            out = ("minibatch", np.concatenate(held), [len(h) for h in held], held_global)
+            held, held_n = [], 0
+            return out
+        return None
+
+    for chunk in chunks:
+        local = shard_indices(chunk, n_envs_global, rank, world)
+        n_mb += 1
+        if merge:
+            if held_n + len(local) > max_batch or len(held) == max_segments or (held and len(chunk) != held_global):
+                op = flush()
+                if op:
+                    yield op
+            held.append(local)
+            held_n += len(local)
+            held_global = len(chunk)
+        else:
+            yield ("minibatch", local, [len(local)], len(chunk))
+            if stats_per_minibatch:
+                yield ("stats",)
+        if cnt % grad_accumulation_steps == 0:
+            op = flush()
+            if op:
+                yield op
+            yield ("step",)
+        cnt += 1
+    op = flush()
+    if op:
+        yield op
+    yield ("log", n_mb)
+
+
 class Collective:
     """Minimal wrapper so that the agent code is identical for 1 rank, gloo (CPU tensors in tests) and
     nccl/RCCL (device tensors wrapping the engine's buffers)."""
