@@ -196,7 +196,8 @@ void launch_sample(const float* hout, int n, int A, const float* u, unsigned lon
 
 void launch_heads_sample(const float* feat, const float* Wh, const float* bh, int n, int H, int A, const float* u,
                          unsigned long long seed, unsigned long long ctr, int32_t* act, float* logp, float* value, float* pack,
-                         float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st);
+                         float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st,
+                         unsigned* done_ctr = nullptr, unsigned* host_flag = nullptr, unsigned ticket = 0);
 void sumsq_set_workspace(double* ws);
 void launch_sumsq(const float* g, long long n, double* out, hipStream_t st);          // out[0] = sum g^2 (deterministic)
 void launch_adam(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr,

@@ -109,6 +109,7 @@ struct mi_ctx {
     unsigned short *fc_wp, *fc_wt;            // bf16 mode: packed fc.weight images ([256][2048] and [2048][256])
     bool fc_packed_valid;
     float *d_pack, *h_pack, *h_rd, *d_rd;     // packed rollout read-back {act,logp,value} x E ; packed {rew,done} upload
+    unsigned *d_done_ctr, *h_flag, roll_ticket;   // rollout step: workgroup counter, host-visible completion ticket (heads_sample_kernel)
     int32_t* s_act; float *s_logp, *s_val; bool staged_valid;
     // recurrent rollout (GRU cell, never trained)
     bool gru_on; float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *h_state, *h_masked, *gru_gi, *gru_gh, *d_done;
@@ -331,6 +332,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(dalloc(&c->d_u, (size_t)E));
     HIPC(dalloc(&c->d_pack, (size_t)3 * E)); HIPC(dalloc(&c->d_rd, (size_t)2 * E));
     HIPC(hipHostMalloc((void**)&c->h_pack, (size_t)3 * E * 4)); HIPC(hipHostMalloc((void**)&c->h_rd, (size_t)2 * E * 4));
+    HIPC(dalloc(&c->d_done_ctr, (size_t)16)); HIPC(hipHostMalloc((void**)&c->h_flag, 64)); *c->h_flag = 0; c->roll_ticket = 0;
     HIPC(dalloc(&c->s_act, (size_t)E)); HIPC(dalloc(&c->s_logp, (size_t)E)); HIPC(dalloc(&c->s_val, (size_t)E)); c->staged_valid = false;
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) {
         HIPC(hipHostMalloc((void**)&c->h_idx_ring[k], (size_t)NB * sizeof(int32_t)));
@@ -385,7 +387,7 @@ int mi_destroy(mi_ctx* c) {
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
     if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc);
-    hipFree(c->stats_ring); hipFree(c->fs_ring); hipFree(c->fs_parts); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd);
+    hipFree(c->stats_ring); hipFree(c->fs_ring); hipFree(c->fs_parts); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd); hipFree(c->d_done_ctr); hipHostFree(c->h_flag);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
@@ -898,9 +900,22 @@ int mi_rollout_step(mi_ctx* c, int32_t t, const float* rew_prev, const float* do
     launch_heads_sample(c->feat, c->params + c->wh_off, c->params + c->bh_off, E, c->H, c->A, du, seed, (unsigned long long)t * E,
                         last ? nullptr : c->act + (size_t)t * E, last ? nullptr : c->logp + (size_t)t * E, c->value + (size_t)t * E,
                         c->h_pack, nullptr, have_rd ? c->h_rd : nullptr, have_rd ? c->rew + (size_t)(t - 1) * E : nullptr,
-                        have_rd ? c->done + (size_t)(t - 1) * E : nullptr, c->stream);
+                        have_rd ? c->done + (size_t)(t - 1) * E : nullptr, c->stream, c->d_done_ctr, c->h_flag, ++c->roll_ticket);
     HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(c->stream));             // kernel end = system-scope release of h_pack; also covers h_rd / u reuse
+    // The last workgroup of the head kernel publishes the ticket after all results (h_pack) are visible to the host and all reads of
+    // h_rd / u are done: spinning on it returns ~5 us earlier than hipStreamSynchronize (12.9 -> 8.1 us for launch + wait of a small
+    // kernel, scratch/synclat.hip), 257 times per iteration.  A kernel that never finishes (fault) falls back to the stream wait,
+    // which reports the error.
+    {
+        const unsigned want = c->roll_ticket;
+        bool seen = false;
+        for (unsigned long long spin = 0; spin < (1ull << 34); ++spin) {
+            if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+            __builtin_ia32_pause();
+            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(c->stream) != hipErrorNotReady) break;     // finished without a ticket, or failed
+        }
+        if (!seen) HIPC(hipStreamSynchronize(c->stream));
+    }
     for (int e = 0; e < E; ++e) {
         if (act_out && !last) act_out[e] = (int64_t)c->h_pack[3 * e];
         if (logp_out && !last) logp_out[e] = c->h_pack[3 * e + 1];

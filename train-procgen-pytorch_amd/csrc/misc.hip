@@ -882,7 +882,8 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
                                                            const float* __restrict__ bh, int n, int H, int A, const float* u,
                                                            unsigned long long seed, unsigned long long ctr, int32_t* act,
                                                            float* logp, float* value, float* pack, float* hout,
-                                                           const float* rd, float* rew_dst, float* done_dst) {
+                                                           const float* rd, float* rew_dst, float* done_dst,
+                                                           unsigned* done_ctr, unsigned* host_flag, unsigned ticket) {
     __shared__ __attribute__((aligned(16))) float s_f[16 * 260];
     __shared__ __attribute__((aligned(16))) float s_w[17 * 260];
     __shared__ float s_z[16 * 17];
@@ -943,21 +944,37 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
     int a_sel = (int)sel;
     if (a_sel > A - 1) a_sel = A - 1;
     const float lp_pick = __shfl(lp, gbase + a_sel, 64);
-    if (o != 0 || e >= n) return;
-    const float lp_sel = lp_pick, val = s_z[el * 17 + A];
-    if (rd) { rew_dst[e] = rwd; done_dst[e] = dn; }        // previous step's reward / done into the (T,E) arrays
-    if (act) act[e] = a_sel;
-    if (logp) logp[e] = lp_sel;
-    if (value) value[e] = val;
-    if (pack) { pack[e * 3] = (float)a_sel; pack[e * 3 + 1] = lp_sel; pack[e * 3 + 2] = val; }
-    if (hout) for (int k = 0; k <= A; ++k) hout[(long long)e * (A + 1) + k] = s_z[el * 17 + k];
+    if (o == 0 && e < n) {
+        const float lp_sel = lp_pick, val = s_z[el * 17 + A];
+        if (rd) { rew_dst[e] = rwd; done_dst[e] = dn; }        // previous step's reward / done into the (T,E) arrays
+        if (act) act[e] = a_sel;
+        if (logp) logp[e] = lp_sel;
+        if (value) value[e] = val;
+        if (pack) { pack[e * 3] = (float)a_sel; pack[e * 3 + 1] = lp_sel; pack[e * 3 + 2] = val; }
+        if (hout) for (int k = 0; k <= A; ++k) hout[(long long)e * (A + 1) + k] = s_z[el * 17 + k];
+    }
+    if (host_flag) {
+        // completion ticket in host-visible memory, written by the LAST workgroup after every workgroup's results are visible system-
+        // wide: the host spins on it instead of waiting for the stream (hipStreamSynchronize returns ~5 us later: scratch/synclat.hip)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = atomicAdd(done_ctr, 1u);
+            if (old == gridDim.x - 1) {
+                *done_ctr = 0;
+                __threadfence_system();
+                __hip_atomic_store(host_flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 void launch_heads_sample(const float* feat, const float* Wh, const float* bh, int n, int H, int A, const float* u,
                          unsigned long long seed, unsigned long long ctr, int32_t* act, float* logp, float* value, float* pack,
-                         float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st) {
+                         float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st,
+                         unsigned* done_ctr, unsigned* host_flag, unsigned ticket) {
     if (n <= 0) return;
     hipLaunchKernelGGL(heads_sample_kernel, dim3((n + 15) / 16), dim3(256), 0, st, feat, Wh, bh, n, H, A, u, seed, ctr, act, logp, value, pack, hout,
-                       rd, rew_dst, done_dst);
+                       rd, rew_dst, done_dst, done_ctr, host_flag, ticket);
 }
 void launch_sample(const float* hout, int n, int A, const float* u, unsigned long long seed, unsigned long long ctr,
                    int32_t* act, float* logp, float* value, hipStream_t st) {
