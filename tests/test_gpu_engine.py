@@ -369,6 +369,21 @@ def test_error_paths():
     with pytest.raises(EngineError):
         eng.put_obs(9, np.zeros((4, 9), np.float32))
     eng.minibatch(np.zeros(0, np.int64), 4, eng.hparams())  # empty local shard of a global minibatch
+    # mi_minibatch_multi: segments must add up, at most 16, no batch-level loss term, not in the per-minibatch-exchange mode
+    idx = np.arange(8)
+    with pytest.raises(EngineError):
+        eng.minibatch_multi(idx, [4, 3], 4, eng.hparams())
+    with pytest.raises(EngineError):
+        eng.minibatch_multi(idx[:0], [0] * 17, 4, eng.hparams())
+    with pytest.raises(EngineError):
+        eng.minibatch_multi(idx, [4, 4], 4, eng.hparams(x_entropy_coef=0.1))
+    eng.set_multirank(1)
+    with pytest.raises(EngineError):
+        eng.minibatch_multi(idx, [4, 4], 4, eng.hparams())
+    eng.set_multirank(0)
+    eng.loss_log(reset=True)
+    eng.minibatch_multi(idx, [4, 0, 4], 4, eng.hparams())   # a segment may be empty (no sample of that minibatch on this rank)
+    assert eng.loss_log(reset=True).shape[0] == 3
     eng.close()
 
 
