@@ -461,32 +461,41 @@ struct SampleTerms {
     float H, ratio, adv, surr1, surr2, v, oldv, ret, vclip, vs1, vs2;
     int act;
 };
+// (All loops over the actions run to the compile-time MAXA under `k < A`: with a run-time bound the per-thread arrays are indexed
+// dynamically and live in scratch memory -- 180 B per thread, the loss kernel then took 35 us for 8192 samples.)
 __device__ __forceinline__ void log_softmax_twice(const float* z, int A, float* lp, float* p) {
     float mx = z[0];
-    for (int a = 1; a < A; ++a) mx = fmaxf(mx, z[a]);
+#pragma unroll
+    for (int a = 1; a < MAXA; ++a) if (a < A) mx = fmaxf(mx, z[a]);
     float s = 0.f;
-    for (int a = 0; a < A; ++a) s += expf(z[a] - mx);
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) if (a < A) s += expf(z[a] - mx);
     const float lse = mx + logf(s);
     float s2 = 0.f;
-    for (int a = 0; a < A; ++a) { lp[a] = z[a] - lse; s2 += expf(lp[a]); }
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) if (a < A) { lp[a] = z[a] - lse; s2 += expf(lp[a]); }
     const float lse2 = logf(s2);                 // Categorical(logits=log_probs) normalises again (policy.py:86-87)
     float s3 = 0.f;
-    for (int a = 0; a < A; ++a) { lp[a] -= lse2; p[a] = expf(lp[a]); s3 += p[a]; }
-    for (int a = 0; a < A; ++a) p[a] /= s3;       // Categorical.probs = softmax(logits)
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) if (a < A) { lp[a] -= lse2; p[a] = expf(lp[a]); s3 += p[a]; }
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) if (a < A) p[a] /= s3;       // Categorical.probs = softmax(logits)
 }
 __device__ __forceinline__ void sample_terms(const LossArgs& a, int s, SampleTerms& t) {
     const float* h = a.hout + (long long)s * (a.A + 1);
     float z[MAXA];
-    for (int k = 0; k < a.A; ++k) z[k] = h[k];
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) z[k] = (k < a.A) ? h[k] : 0.f;
     log_softmax_twice(z, a.A, t.lp, t.p);
     const int gi = a.idx[s];
     t.act = a.act[gi];
     t.adv = a.adv[gi]; t.ret = a.ret[gi]; t.oldv = a.old_value[gi];
     t.v = h[a.A];
-    float H = 0.f;
-    for (int k = 0; k < a.A; ++k) H -= t.p[k] * t.lp[k];
+    float H = 0.f, lp_act = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) if (k < a.A) { H -= t.p[k] * t.lp[k]; lp_act = (k == t.act) ? t.lp[k] : lp_act; }
     t.H = H;
-    t.ratio = expf(t.lp[t.act] - a.old_logp[gi]);
+    t.ratio = expf(lp_act - a.old_logp[gi]);
     t.surr1 = t.ratio * t.adv;
     t.surr2 = fminf(fmaxf(t.ratio, 1.f - a.hp.eps_clip), 1.f + a.hp.eps_clip) * t.adv;
     t.vclip = t.oldv + fminf(fmaxf(t.v - t.oldv, -a.hp.eps_clip), a.hp.eps_clip);
@@ -494,7 +503,10 @@ __device__ __forceinline__ void sample_terms(const LossArgs& a, int s, SampleTer
     t.vs2 = (t.vclip - t.ret) * (t.vclip - t.ret);
 }
 
-int loss_blocks(int n) { return (n + 255) / 256; }
+// samples per workgroup of the loss kernels: one wave -- 128 workgroups for an 8192-sample minibatch (the exp / log heavy per-sample
+// work ran on 32 CUs with four-wave workgroups: 35 us)
+constexpr int LOSS_BLK = 64;
+int loss_blocks(int n) { return (n + LOSS_BLK - 1) / LOSS_BLK; }
 
 __device__ __forceinline__ void loss_bwd_sample(const LossArgs& a, int s, const SampleTerms& t) {
     const float ib = a.inv_n_global;
@@ -505,9 +517,13 @@ __device__ __forceinline__ void loss_bwd_sample(const LossArgs& a, int s, const 
     float plq = 0.f;
     float lq[MAXA];
     const bool xe = a.hp.x_entropy_coef != 0.f;
-    if (xe) for (int k = 0; k < a.A; ++k) { lq[k] = logf(a.stats[8 + k]); plq += t.p[k] * lq[k]; }
+    if (xe) {
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) if (k < a.A) { lq[k] = logf(a.stats[8 + k]); plq += t.p[k] * lq[k]; }
+    }
     float* d = a.dY + (long long)s * (a.A + 1);
-    for (int k = 0; k < a.A; ++k) {
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) if (k < a.A) {
         float gk = g_lp * ((k == t.act ? 1.f : 0.f) - t.p[k]);
         gk += cH * (-t.p[k] * (t.lp[k] + t.H));
         if (xe) gk += a.hp.x_entropy_coef * ib * t.p[k] * (lq[k] - plq);
@@ -521,72 +537,81 @@ __device__ __forceinline__ void loss_bwd_sample(const LossArgs& a, int s, const 
     else gv = (t.v - t.ret) + (t.vclip - t.ret) * inr;
     d[a.A] = a.hp.value_coef * 0.5f * ib * gv;
 }
-__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(LOSS_BLK) void loss_bwd_kernel(LossArgs a) {
+    const int s = blockIdx.x * LOSS_BLK + threadIdx.x;
     if (s >= a.n) return;
     SampleTerms t;
     sample_terms(a, s, t);
     loss_bwd_sample(a, s, t);
 }
-// one 256-sample block of the loss: sums over the samples s < s_end of this block -> partial row `row` (per value: wave sums,
-// then the four waves in order -- the sums of block_sum256 with one barrier instead of two per value).  BWD: the loss has no
+// one LOSS_BLK-sample block of the loss: sums over the samples s < s_end of this block -> partial row `row` (per value: wave sums,
+// then the waves in order, one barrier per block).  BWD: the loss has no
 // batch-level term (x_entropy_coef == 0), so the gradient of the sample goes out in the same pass.
 template <bool BWD>
 __device__ __forceinline__ void loss_fwd_block(const LossArgs& a, int s, int s_end, int row) {
-    __shared__ float sw[4][8 + MAXA];
+    constexpr int NW = LOSS_BLK / 64;
+    __shared__ float sw[NW][8 + MAXA];
     SampleTerms t;
     float pi = 0.f, vm = 0.f, H = 0.f;
     float pa[MAXA];
+#pragma unroll
     for (int k = 0; k < MAXA; ++k) pa[k] = 0.f;
     if (s < s_end) {
         sample_terms(a, s, t);
         pi = fminf(t.surr1, t.surr2);
         vm = fmaxf(t.vs1, t.vs2);
         H = t.H;
-        for (int k = 0; k < a.A; ++k) pa[k] = t.p[k];
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) if (k < a.A) pa[k] = t.p[k];
         if (BWD) loss_bwd_sample(a, s, t);
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float r = wave_sum(pi); if (lane == 0) sw[w][0] = r;
     r = wave_sum(vm);       if (lane == 0) sw[w][1] = r;
     r = wave_sum(H);        if (lane == 0) sw[w][2] = r;
-    for (int k = 0; k < a.A; ++k) { r = wave_sum(pa[k]); if (lane == 0) sw[w][8 + k] = r; }
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) if (k < a.A) { r = wave_sum(pa[k]); if (lane == 0) sw[w][8 + k] = r; }
     __syncthreads();
     const int k = threadIdx.x;
-    if (k < 3 || (k >= 8 && k < 8 + a.A)) a.partial[(long long)row * (8 + a.A) + k] = sw[0][k] + sw[1][k] + sw[2][k] + sw[3][k];
+    if (k < 3 || (k >= 8 && k < 8 + a.A)) {
+        float t = sw[0][k];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) t += sw[w2][k];
+        a.partial[(long long)row * (8 + a.A) + k] = t;
+    }
 }
-__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a) {
-    loss_fwd_block<false>(a, blockIdx.x * 256 + threadIdx.x, a.n, blockIdx.x);
+__global__ __launch_bounds__(LOSS_BLK) void loss_fwd_kernel(LossArgs a) {
+    loss_fwd_block<false>(a, blockIdx.x * LOSS_BLK + threadIdx.x, a.n, blockIdx.x);
 }
-// segment k owns ceil(len_k / 256) consecutive blocks (no block straddles two minibatches)
+// segment k owns ceil(len_k / LOSS_BLK) consecutive blocks (no block straddles two minibatches)
 __device__ __forceinline__ void seg_of_block(const SegTab& st, int b, int& k, int& first) {
     first = 0;
     for (k = 0; k < st.n_seg - 1; ++k) {
-        const int nb = (st.start[k + 1] - st.start[k] + 255) / 256;
+        const int nb = (st.start[k + 1] - st.start[k] + LOSS_BLK - 1) / LOSS_BLK;
         if (b < first + nb) break;
         first += nb;
     }
 }
 template <bool BWD>
-__global__ __launch_bounds__(256) void loss_fwd_seg_kernel(LossArgs a, SegTab st) {
+__global__ __launch_bounds__(LOSS_BLK) void loss_fwd_seg_kernel(LossArgs a, SegTab st) {
     int k, first;
     seg_of_block(st, blockIdx.x, k, first);
-    loss_fwd_block<BWD>(a, st.start[k] + (blockIdx.x - first) * 256 + threadIdx.x, st.start[k + 1], blockIdx.x);
+    loss_fwd_block<BWD>(a, st.start[k] + (blockIdx.x - first) * LOSS_BLK + threadIdx.x, st.start[k + 1], blockIdx.x);
 }
 int loss_blocks_seg(const SegTab& st) {
     int nb = 0;
-    for (int k = 0; k < st.n_seg; ++k) nb += (st.start[k + 1] - st.start[k] + 255) / 256;
+    for (int k = 0; k < st.n_seg; ++k) nb += (st.start[k + 1] - st.start[k] + LOSS_BLK - 1) / LOSS_BLK;
     return nb;
 }
 void launch_loss_fwd_seg(const LossArgs& a, const SegTab& st, bool with_bwd, hipStream_t stream) {
     const int nb = loss_blocks_seg(st);
     if (nb <= 0) return;
-    if (with_bwd) hipLaunchKernelGGL(loss_fwd_seg_kernel<true>, dim3(nb), dim3(256), 0, stream, a, st);
-    else hipLaunchKernelGGL(loss_fwd_seg_kernel<false>, dim3(nb), dim3(256), 0, stream, a, st);
+    if (with_bwd) hipLaunchKernelGGL(loss_fwd_seg_kernel<true>, dim3(nb), dim3(LOSS_BLK), 0, stream, a, st);
+    else hipLaunchKernelGGL(loss_fwd_seg_kernel<false>, dim3(nb), dim3(LOSS_BLK), 0, stream, a, st);
 }
 void launch_loss_fwd(const LossArgs& a, hipStream_t st) {
     if (a.n <= 0) return;
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(loss_blocks(a.n)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(loss_blocks(a.n)), dim3(LOSS_BLK), 0, st, a);
 }
 
 // phase 1: block partials -> this rank's contribution to the GLOBAL-minibatch means (x inv_n_global)
@@ -625,7 +650,7 @@ __global__ void loss_finalize_seg_kernel(LossArgs a, SegTab st, int phase, float
                                          float* log_base) {
     const int k = blockIdx.x;
     int first = 0;
-    for (int j = 0; j < k; ++j) first += (st.start[j + 1] - st.start[j] + 255) / 256;
+    for (int j = 0; j < k; ++j) first += (st.start[j + 1] - st.start[j] + LOSS_BLK - 1) / LOSS_BLK;
     a.partial += (long long)first * (8 + a.A);
     a.stats = stats_base + 32 * k;
     if (fs_parts && threadIdx.x == 0) {                 // second half of the feature-sparsity metric: mean over the d columns
@@ -633,7 +658,7 @@ __global__ void loss_finalize_seg_kernel(LossArgs a, SegTab st, int phase, float
         for (int j = 0; j < FS_PARTS; ++j) tot += fs_parts[k * FS_PARTS + j];
         fs_out[k] = (float)(tot / fs_d);
     }
-    loss_finalize_body(a, (st.start[k + 1] - st.start[k] + 255) / 256, phase, fs_parts ? fs_out + k : nullptr, log_base ? log_base + 8 * k : nullptr);
+    loss_finalize_body(a, (st.start[k + 1] - st.start[k] + LOSS_BLK - 1) / LOSS_BLK, phase, fs_parts ? fs_out + k : nullptr, log_base ? log_base + 8 * k : nullptr);
 }
 // phase 2 of n_rec records at once (after the cross-rank sum of the statistics ring): record k from stats_base + 32 k, fs_base[k]
 __global__ void loss_finalize_records_kernel(LossArgs a, float* stats_base, const float* fs_base, float* log_base) {
@@ -655,7 +680,7 @@ void launch_loss_finalize(const LossArgs& a, int nblk, int phase, const float* f
 
 void launch_loss_bwd(const LossArgs& a, hipStream_t st) {
     if (a.n <= 0) return;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(loss_blocks(a.n)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(loss_blocks(a.n)), dim3(LOSS_BLK), 0, st, a);
 }
 
 // feature-sparsity metric (common/model.py:207): mean_j max_b tanh(|100*relu(h_bj)|)
