@@ -368,35 +368,35 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 // All conv layers of one backward pass in ONE launch (blockIdx.y = layer): each layer's workgroups left their slabs in
 // its own region of the workspace.  Same per-element summation order as reduce_slabs_kernel.
 __global__ __launch_bounds__(1024) void reduce_all_slabs_kernel(const float* __restrict__ ws, float* __restrict__ grads, const SlabDesc* __restrict__ desc) {
-    __shared__ float sh[32][33];
+    __shared__ f32x4 sh[32][33];
     const SlabDesc d = desc[blockIdx.y];
     const int ex = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + ex;
-    if (blockIdx.x * 32 >= d.slab_len) return;                    // wave-uniform: whole workgroup beyond this layer's slab
+    const int e = (blockIdx.x * 32 + ex) * 4;                     // 4 consecutive elements per thread (slab lengths, offsets and the
+    if (blockIdx.x * 128 >= d.slab_len) return;                   // weight / bias boundary are multiples of 4): 512-byte rows per half-wave
     const float* partial = ws + d.src_off;
-    float s = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (e < d.slab_len) {
         int b = g;
         for (; b + 96 < d.nslab; b += 128) {                      // 4 loads in flight; adds stay in slab order
-            const float v0 = partial[(long long)b * d.slab_len + e], v1 = partial[(long long)(b + 32) * d.slab_len + e];
-            const float v2 = partial[(long long)(b + 64) * d.slab_len + e], v3 = partial[(long long)(b + 96) * d.slab_len + e];
+            const f32x4 v0 = *(const f32x4*)(partial + (long long)b * d.slab_len + e), v1 = *(const f32x4*)(partial + (long long)(b + 32) * d.slab_len + e);
+            const f32x4 v2 = *(const f32x4*)(partial + (long long)(b + 64) * d.slab_len + e), v3 = *(const f32x4*)(partial + (long long)(b + 96) * d.slab_len + e);
             s += v0; s += v1; s += v2; s += v3;
         }
-        for (; b < d.nslab; b += 32) s += partial[(long long)b * d.slab_len + e];
+        for (; b < d.nslab; b += 32) s += *(const f32x4*)(partial + (long long)b * d.slab_len + e);
     }
     sh[g][ex] = s;
     __syncthreads();
     if (g == 0 && e < d.slab_len) {
-        float t = 0.f;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 32; ++k) t += sh[k][ex];
-        if (e < d.n_w) grads[d.w_off + e] += t;
-        else grads[d.b_off + e - d.n_w] += t;
+        float* dst = (e < d.n_w) ? grads + d.w_off + e : grads + d.b_off + e - d.n_w;
+        dst[0] += t.x; dst[1] += t.y; dst[2] += t.z; dst[3] += t.w;
     }
 }
 void launch_reduce_all_slabs(const float* ws, float* grads, const SlabDesc* d_desc, int n_desc, int max_slab_len, hipStream_t st) {
     if (n_desc <= 0) return;
-    hipLaunchKernelGGL(reduce_all_slabs_kernel, dim3((max_slab_len + 31) / 32, n_desc), dim3(1024), 0, st, ws, grads, d_desc);
+    hipLaunchKernelGGL(reduce_all_slabs_kernel, dim3((max_slab_len + 127) / 128, n_desc), dim3(1024), 0, st, ws, grads, d_desc);
 }
 void launch_reduce_slabs(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b, hipStream_t st) {
     if (nslab <= 0) return;
