@@ -928,7 +928,25 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
     const int el = tid >> 4, o = tid & 15, e = e0 + el;
     float rwd = 0.f, dn = 0.f;
     if (rd && o == 0 && e < n) { rwd = rd[e]; dn = rd[n + e]; }          // (host-visible staging) issued first: latency hidden by the dots
-    if ((H & 3) == 0) {
+    if (H == 256) {
+        // the IMPALA width: all 9 loads of a thread are issued before the first LDS store (the general loop below divides by a
+        // run-time H and waits for every load before the next: 9 memory latencies in a row, half of this kernel's time)
+        f32x4 rf[4], rw[5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = tid + j * 256, r = k >> 6, kk = (k & 63) * 4;
+            rf[j] = (e0 + r < n) ? *(const f32x4*)(feat + (long long)(e0 + r) * 256 + kk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = tid + j * 256, r = k >> 6, kk = (k & 63) * 4;
+            rw[j] = (r <= A) ? *(const f32x4*)(Wh + (long long)r * 256 + kk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = tid + j * 256; *(f32x4*)(s_f + (k >> 6) * 260 + (k & 63) * 4) = rf[j]; }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { const int k = tid + j * 256; if ((k >> 6) <= A) *(f32x4*)(s_w + (k >> 6) * 260 + (k & 63) * 4) = rw[j]; }
+    } else if ((H & 3) == 0) {
         const int H4 = H >> 2;
         for (int k = tid; k < 16 * H4; k += 256) {
             const int r = k / H4, kk = (k % H4) * 4;
@@ -948,6 +966,13 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
         const float* f = s_f + el * 260;
         float acc = 0.f;
         int k = 0;
+        if (H == 256) {                                   // same order of operations, LDS reads of 8 steps in flight
+#pragma unroll 8
+            for (; k < 256; k += 4) {
+                const f32x4 fv = *(const f32x4*)(f + k), ww = *(const f32x4*)(w + k);
+                acc += fv.x * ww.x + fv.y * ww.y + fv.z * ww.z + fv.w * ww.w;
+            }
+        }
         for (; k + 4 <= H; k += 4) {
             const f32x4 fv = *(const f32x4*)(f + k), ww = *(const f32x4*)(w + k);
             acc += fv.x * ww.x + fv.y * ww.y + fv.z * ww.z + fv.w * ww.w;
@@ -956,31 +981,69 @@ __global__ __launch_bounds__(256) void heads_sample_kernel(const float* __restri
         s_z[el * 17 + oo] = acc + bh[oo];
     }
     __syncthreads();
-    // the 16 lanes of an env sit in one wave (lane = 16*(el & 3) + o): terms travel by ds_bpermute, no LDS round trips / barriers
+    // The 16 lanes of an env sit in one wave (lane = 16*(el & 3) + o).  A lane publishes its term in the env's 64-byte LDS row and
+    // reads the whole row back with four 16-byte reads (same wave: LDS executes a wave's operations in order, no barrier), then adds
+    // the A terms in action order from registers.  (A run-time loop of 15 ds_bpermute + add, each waiting for the previous, was ~40 %
+    // of this kernel: six such loops.)
+    __shared__ __attribute__((aligned(16))) float s_t[16 * 16];
     const bool lane_on = o < A;
-    const int gbase = threadIdx.x & 48;                                   // first lane of this env's group inside the wave
-    const float z = lane_on ? s_z[el * 17 + o] : 0.f;
-    float mx = __shfl(z, gbase, 64);
-    for (int k = 1; k < A; ++k) mx = fmaxf(mx, __shfl(z, gbase + k, 64));
+    auto row = [&](float term, float (&v)[16]) {
+        __builtin_amdgcn_wave_barrier();
+        s_t[el * 16 + o] = term;
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 a0 = *(const f32x4*)(s_t + el * 16), a1 = *(const f32x4*)(s_t + el * 16 + 4);
+        const f32x4 a2 = *(const f32x4*)(s_t + el * 16 + 8), a3 = *(const f32x4*)(s_t + el * 16 + 12);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        v[8] = a2.x; v[9] = a2.y; v[10] = a2.z; v[11] = a2.w; v[12] = a3.x; v[13] = a3.y; v[14] = a3.z; v[15] = a3.w;
+    };
     auto group_sum = [&](float term) {                    // sum over the env's A lanes, in action order
+        float v[16];
+        row(term, v);
         float t = 0.f;
-        for (int k = 0; k < A; ++k) t += __shfl(term, gbase + k, 64);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < A) t += v[k];
         return t;
     };
+    const float z = lane_on ? s_z[el * 17 + o] : 0.f;
+    float mx;
+    {
+        float v[16];
+        row(z, v);
+        mx = v[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) if (k < A) mx = fmaxf(mx, v[k]);
+    }
     const float s1 = group_sum(lane_on ? expf(z - mx) : 0.f);
     float lp = z - (mx + logf(s1));
     const float s2 = group_sum(lane_on ? expf(lp) : 0.f);
     lp -= logf(s2);                                        // Categorical(logits=log_probs) normalises again (policy.py:86-87)
     const float pr = lane_on ? expf(lp) : 0.f;
     float cdf = 0.f;
-    for (int k = 0; k < A; ++k) { const float v = __shfl(pr, gbase + k, 64); cdf += (k <= o) ? v : 0.f; }      // prefix in action order
+    {
+        float v[16];
+        row(pr, v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < A) cdf += (k <= o) ? v[k] : 0.f;      // prefix in action order
+    }
     const float uu = (e < n) ? (u ? u[e] : philox_uniform(seed, ctr + e)) : 0.f;
     const float mark = (lane_on && cdf <= uu) ? (float)(o + 1) : 0.f;
     float sel = 0.f;
-    for (int k = 0; k < A; ++k) sel = fmaxf(sel, __shfl(mark, gbase + k, 64));
+    {
+        float v[16];
+        row(mark, v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < A) sel = fmaxf(sel, v[k]);
+    }
     int a_sel = (int)sel;
     if (a_sel > A - 1) a_sel = A - 1;
-    const float lp_pick = __shfl(lp, gbase + a_sel, 64);
+    float lp_pick;
+    {
+        float v[16];
+        row(lp, v);
+        lp_pick = v[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) lp_pick = (k == a_sel) ? v[k] : lp_pick;
+    }
     if (o == 0 && e < n) {
         const float lp_sel = lp_pick, val = s_z[el * 17 + A];
         if (rd) { rew_dst[e] = rwd; done_dst[e] = dn; }        // previous step's reward / done into the (T,E) arrays
