@@ -118,6 +118,8 @@ void conv_shape_dims(ConvShape s, int* cin, int* cout, int* hw);
 void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st);     // conv_bf16.hip (bf16 MFMA)
 void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st);
 void launch_conv1_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, hipStream_t st);
+void launch_pack_conv1_bank(const float* w, unsigned short* bank, hipStream_t st);   // ConvArgs.wbank of launch_conv1_pool_fwd_bf16 (optional)
+int  conv1_bank_elems();
 void launch_conv1_pool_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, void* p_out, uint8_t* p_arg, hipStream_t st);
 void launch_conv1_wgrad_bf16(const WgradArgs& a, const unsigned short* lut16, hipStream_t st);
 int  wgrad_grid_bf16(ConvShape s, int n);                                  // -1: shape handled by conv.hip

@@ -899,6 +899,17 @@ using C1P = C1T<9>;
 #ifndef C1P_SC
 #define C1P_SC 24         // conv-output tile pixel stride in LDS (bf16 elements)
 #endif
+// block1.conv forward bank in the LDS layout of the conv1 kernels: [16 filters][C1_WS], K index k = tap*4 + ci (ci == 3 and k >= 36 zero)
+__global__ void pack_conv1_bank_kernel(const float* __restrict__ w, unsigned short* __restrict__ bank) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 16 * C1_WS) return;
+    const int j = e / C1_WS, k = e % C1_WS, tap = k / 4, ci = k % 4;
+    bank[e] = f2bf((k < 36 && ci < 3) ? w[(j * 9 + tap) * 3 + ci] : 0.f);
+}
+void launch_pack_conv1_bank(const float* w, unsigned short* bank, hipStream_t st) {
+    hipLaunchKernelGGL(pack_conv1_bank_kernel, dim3((16 * C1_WS + 255) / 256), dim3(256), 0, st, w, bank);
+}
+int conv1_bank_elems() { return 16 * C1_WS; }
 __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, const unsigned short* lut16, unsigned short* p_out, uint8_t* p_arg) {
     __shared__ __attribute__((aligned(16))) unsigned short s_in[C1P::NPIX * 4];
     __shared__ __attribute__((aligned(16))) unsigned short s_w[16 * C1_WS];
@@ -910,11 +921,16 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
 #ifdef WG_TIMING
     long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
 #endif
-    for (int e = tid; e < 16 * C1_WS; e += 256) {
-        const int j = e / C1_WS, k = e % C1_WS, tap = k / 4, ci = k % 4;
-        s_w[e] = f2bf((k < 36 && ci < 3) ? a.w[(j * 9 + tap) * 3 + ci] : 0.f);
+    if (a.wbank) {                                         // pre-packed by pack_conv1_bank_kernel: one 16-byte load per thread (the rollout-sized
+        if (tid < 16 * C1_WS / 8) ((uint4*)s_w)[tid] = ((const uint4*)a.wbank)[tid];      // launch runs this prologue for 2 items only)
+    } else {
+        for (int e = tid; e < 16 * C1_WS; e += 256) {
+            const int j = e / C1_WS, k = e % C1_WS, tap = k / 4, ci = k % 4;
+            s_w[e] = f2bf((k < 36 && ci < 3) ? a.w[(j * 9 + tap) * 3 + ci] : 0.f);
+        }
     }
-    for (int e = tid; e < C1P::NPIX * 4; e += 256) s_in[e] = 0;
+    static_assert((C1P::NPIX * 4) % 8 == 0, "16-byte zero fill");
+    for (int e = tid; e < C1P::NPIX * 4 / 8; e += 256) ((uint4*)s_in)[e] = (uint4){0u, 0u, 0u, 0u};
     if (tid < 9 * 8) ((unsigned*)s_c)[(tid >> 3) * 65 * (C1P_SC / 2) + (tid & 7)] = MI_KEY_MIN2;
     float bias4[4];                                        // output channels 4*kq .. 4*kq+3 (the MFMA's row quad)
 #pragma unroll

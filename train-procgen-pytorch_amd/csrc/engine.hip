@@ -106,6 +106,7 @@ struct mi_ctx {
     double* sumsq; float* gnorm;
     float* d_u; float* d_lp;
     unsigned short* banks; BankDesc* d_bank_desc; int n_banks;   // bf16 mode: pre-packed conv filter banks
+    unsigned short* c1_bank;                                   // bf16 mode: block1.conv forward bank (conv1 kernels' LDS layout)
     unsigned short *fc_wp, *fc_wt;            // bf16 mode: packed fc.weight images ([256][2048] and [2048][256])
     bool fc_packed_valid;
     float *d_pack, *h_pack, *h_rd, *d_rd;     // packed rollout read-back {act,logp,value} x E ; packed {rew,done} upload
@@ -346,7 +347,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->multirank = 0; c->pending_n = -1; c->sal_dc = nullptr; c->sal_dx = nullptr; c->sal_src = nullptr;
     c->fc_wp = c->fc_wt = nullptr; c->fc_packed_valid = false;
     if (c->bf) { HIPC(dalloc(&c->fc_wp, (size_t)256 * 2048)); HIPC(dalloc(&c->fc_wt, (size_t)256 * 2048)); }
-    c->banks = nullptr; c->d_bank_desc = nullptr; c->n_banks = 0;
+    c->banks = nullptr; c->d_bank_desc = nullptr; c->n_banks = 0; c->c1_bank = nullptr;
+    if (c->bf && c->cfg.arch == MI_ARCH_IMPALA) HIPC(dalloc(&c->c1_bank, (size_t)conv1_bank_elems()));
     for (auto& L : c->convs) { L.bank_f = -1; L.bank_d = -1; }
     if (c->bf) {
         std::vector<BankDesc> desc;
@@ -386,7 +388,7 @@ int mi_destroy(mi_ctx* c) {
     if (c->stage_frames) hipFree(c->stage_frames);
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
-    if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc);
+    if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc); if (c->c1_bank) hipFree(c->c1_bank);
     hipFree(c->stats_ring); hipFree(c->fs_ring); hipFree(c->fs_parts); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd); hipFree(c->d_done_ctr); hipHostFree(c->h_flag);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
@@ -663,6 +665,7 @@ static void fc_refresh(mi_ctx* c) {
     if (c->bf && !c->fc_packed_valid) {
         launch_fc_pack(c->params + c->fc.w_off, c->fc_wp, c->fc_wt, 256, 2048, c->stream);
         launch_pack_banks(c->params, c->banks, c->d_bank_desc, c->n_banks, c->stream);
+        if (c->c1_bank && !c->convs.empty()) launch_pack_conv1_bank(c->params + c->convs[0].w_off, c->c1_bank, c->stream);
         c->fc_packed_valid = true;
     }
 }
@@ -677,7 +680,7 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
             if (b == 0 && c->bf) {           // block1.conv + max pool fused: the 64x64x16 conv output never reaches HBM
                 ConvArgs a{};
                 a.in = src.base; a.idx = src.idx; a.in_base = src.first; a.w = c->params + L[0].w_off; a.bias = c->params + L[0].b_off;
-                a.n = n; a.bf16 = 1; a.lut16 = c->lut16;
+                a.n = n; a.bf16 = 1; a.lut16 = c->lut16; a.wbank = c->c1_bank;
                 const double px = (double)n * 64 * 64;
                 ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, px * 3.0 + 2.0 * (2.0 * px * 16 + px / 4 * 16), px * 18.0 * 3 * 16);      // conv I + X, pool X + p
                 launch_conv1_pool_fwd_bf16(a, c->lut16, k.P0, k.PI, c->stream);
