@@ -233,7 +233,13 @@ __global__ void fc_tn_reduce_kernel(const float* __restrict__ ws, int split, lon
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     float s = 0.f;
-    for (int z = 0; z < split; ++z) s += ws[(long long)z * total + e];
+    int z = 0;
+    for (; z + 4 <= split; z += 4) {                           // 4 loads in flight, adds in split order
+        const float t0 = ws[(long long)z * total + e], t1 = ws[(long long)(z + 1) * total + e];
+        const float t2 = ws[(long long)(z + 2) * total + e], t3 = ws[(long long)(z + 3) * total + e];
+        s += t0; s += t1; s += t2; s += t3;
+    }
+    for (; z < split; ++z) s += ws[(long long)z * total + e];
     gW[e] += s;
 }
 // A: fp32 [K][M], B: bf16 [K][N], gW fp32 [M][N] accumulated; ws: >= split*M*N floats.  M % 64 == 0, N % 128 == 0.
