@@ -357,6 +357,46 @@ def test_policy_step_sampling():
     eng.close()
 
 
+def test_contexts_do_not_share_workspaces():
+    """Two contexts live at once (PPO builds a training and a validation engine), the second destroyed first: the survivor's
+    minibatch + optimizer step must be bit-equal to a run where it was alone.  (Split-K, column-sum and grad-norm workspaces were
+    process globals once: destroying any context silently switched the others to other reduction paths, or left them on freed memory.)"""
+    from mi355 import engine as M, layout
+    T, E, A, B = 4, 8, 15, 32
+    rng = np.random.default_rng(9)
+    frames = rng.integers(0, 256, size=(T + 1, E, 64, 64, 3), dtype=np.uint8)
+    act = rng.integers(0, A, (T, E)); logp = (np.log(1 / A) + 0.2 * rng.standard_normal((T, E))).astype(np.float32)
+    val = rng.standard_normal((T + 1, E)).astype(np.float32); rew = rng.standard_normal((T, E)).astype(np.float32)
+    done = (rng.random((T, E)) < 0.2).astype(np.float32)
+    params = layout.flatten(shapes_for("impala", A), golden_params("impala"))
+
+    def run(with_neighbour):
+        a = make_engine("impala", T, E, A, B)
+        a.set_params(params)
+        for t in range(T + 1):
+            a.put_obs(t, frames[t])
+        a.write_field(M.F_ACT, act.astype(np.float32)); a.write_field(M.F_LOGP, logp); a.write_field(M.F_VALUE, val)
+        a.write_field(M.F_REW, rew); a.write_field(M.F_DONE, done)
+        a.compute_estimates(0.999, 0.95, True, True)
+        if with_neighbour:
+            b = make_engine("impala", T, E, A, B)
+            b.set_params(params * 0.5)
+            b.put_obs(0, frames[1])
+            b.minibatch(np.arange(8), 8, b.hparams())        # the neighbour uses its own workspaces ...
+            b.optimizer_step(5e-4, 0.5, 1)
+            b.close()                                        # ... and takes nothing of a's with it
+        a.minibatch(np.arange(T * E), T * E, a.hparams())
+        g = a.get_grads()
+        gn = a.optimizer_step(5e-4, 0.5, 1, want_norm=True)
+        out = (g, gn, a.get_params(), a.loss_log()[0])
+        a.close()
+        return out
+
+    alone, shared = run(False), run(True)
+    assert np.array_equal(alone[0], shared[0]) and alone[1] == shared[1]
+    assert np.array_equal(alone[2], shared[2]) and np.array_equal(alone[3], shared[3])
+
+
 def test_error_paths():
     from mi355.engine import Engine, EngineError
     with pytest.raises(EngineError):

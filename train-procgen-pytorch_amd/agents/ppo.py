@@ -80,9 +80,7 @@ class PPO(BaseAgent):
                                        mlp_width=getattr(emb, "mid_weight", 0), out_dim=emb.output_dim, device=dev_index,
                                        precision=self.precision)
             storage_valid.attach_engine(self.engine_valid)
-            if policy.is_recurrent():
-                g = policy.gru.gru
-                self.engine_valid.set_gru(*(t.detach().numpy() for t in (g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)))
+            policy.attach_aux_engine(self.engine_valid)          # frozen GRU weights, now and after load_state_dict
         self.optimizer = DeviceAdam(policy, self.engine, learning_rate, eps=1e-5)
         self._grads_t = self._stats_t = self._ring_t = None
         if self.coll.active:

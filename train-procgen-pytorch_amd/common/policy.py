@@ -54,10 +54,19 @@ class CategoricalPolicy(nn.Module):
 
     def attach_engine(self, engine):
         object.__setattr__(self, "engine", engine)
+        object.__setattr__(self, "_aux_engines", [])
         self.sync_to_device()
+        self._upload_gru(engine)
+
+    def attach_aux_engine(self, engine):
+        """An inference-only twin (PPO's validation engine): it receives the frozen GRU now and again on load_state_dict."""
+        self._aux_engines.append(engine)
+        self._upload_gru(engine)
+
+    def _upload_gru(self, engine):
         if self.recurrent:
             g = self.gru.gru
-            engine.set_gru(*(t.detach().numpy() for t in (g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)))
+            engine.set_gru(*(t.detach().cpu().numpy() for t in (g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)))
 
     def sync_to_device(self):
         self.engine.set_params(layout.flatten(self.param_shapes(), self._host_tensors()))
@@ -85,6 +94,10 @@ class CategoricalPolicy(nn.Module):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         if self.engine is not None:
             self.sync_to_device()
+            # the GRU is not part of the flat parameter vector (never trained, A9): a checkpoint's GRU replaces the freshly
+            # initialised one the engines were given at construction (train.py:257-263 loads AFTER building the agent)
+            for e in [self.engine] + list(getattr(self, "_aux_engines", [])):
+                self._upload_gru(e)
         return out
 
     # ---------------------------------------------------------------- reference API

@@ -138,6 +138,7 @@ struct GemmArgs {
     int relu_out;          // max(c,0) in the epilogue (after bias)
     int accumulate;        // C += result
     int a_bf16, b_bf16, mask_bf16, c_bf16;   // the operand / mask / output is bf16 in HBM (arithmetic stays fp32)
+    float* ws; size_t ws_floats;             // split-K slab workspace of the calling context (null: never split)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);
 
@@ -148,7 +149,7 @@ void launch_maxpool_fwd_bf16(const void* in, void* out, uint8_t* arg, int n, int
 void launch_maxpool_bwd_bf16(const void* dout, const uint8_t* arg, void* din, int n, int hw, int c, hipStream_t st);
 void launch_reduce_slabs(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b,
                          hipStream_t st);
-void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, hipStream_t st);
+void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, float* col_ws /* >= 64 x 4096 floats */, hipStream_t st);
 void launch_gather_rows(const float* src, const int32_t* idx, long long base, float* dst, int n, int d, hipStream_t st);
 
 struct LossHP { float eps_clip, value_coef, entropy_coef, x_entropy_coef, entropy_mult, fs_coef; };
@@ -169,8 +170,6 @@ void launch_loss_fwd(const LossArgs& a, hipStream_t st);
 // phase bit 0: block partials -> this rank's share of the global means; bit 1: derived terms + log record
 void launch_loss_finalize(const LossArgs& a, int nblk, int phase, const float* fs_ptr, float* log_slot, hipStream_t st);
 void launch_logp_all(const float* hout, int n, int A, float* lp_out, float* value_out, hipStream_t st);
-void gemm_set_workspace(float* ws, size_t floats);
-void colsum_set_workspace(float* ws);   // >= 64 * max_N floats
 void launch_loss_bwd(const LossArgs& a, hipStream_t st);
 // several global minibatches in one gathered batch (mi_minibatch_multi): samples of segment k are [start[k], start[k+1])
 constexpr int MI_MAX_SEG = 16;
@@ -200,8 +199,7 @@ void launch_heads_sample(const float* feat, const float* Wh, const float* bh, in
                          unsigned long long seed, unsigned long long ctr, int32_t* act, float* logp, float* value, float* pack,
                          float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st,
                          unsigned* done_ctr = nullptr, unsigned* host_flag = nullptr, unsigned ticket = 0);
-void sumsq_set_workspace(double* ws);
-void launch_sumsq(const float* g, long long n, double* out, hipStream_t st);          // out[0] = sum g^2 (deterministic)
+void launch_sumsq(const float* g, long long n, double* out, double* part, hipStream_t st);          // out[0] = sum g^2 (deterministic)
 void launch_adam(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr,
                  float beta1, float beta2, float eps, float step_size_scale, float bc2_sqrt, float* gnorm_out,
                  hipStream_t st);

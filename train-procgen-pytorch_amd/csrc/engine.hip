@@ -28,6 +28,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
             return fail(-2, std::string(#x) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
     } while (0)
 #define ARG(c, msg) do { if (!(c)) return fail(-1, std::string("invalid argument: ") + msg); } while (0)
+#define NETCHK(c) do { if (!(c)->net_err.empty()) { std::string m_ = (c)->net_err; (c)->net_err.clear(); return fail(-4, m_); } } while (0)
 
 enum TKind { K_PLAIN = 0, K_CONVW, K_FCW };
 struct TensorDesc {
@@ -95,7 +96,7 @@ struct mi_ctx {
     float* slabs; size_t slab_floats;
     void* sal_dc; float* sal_dx; const float* sal_src;       // value saliency: conv-out gradient temp (bf16 mode), input gradient, where net_backward left block 1's gradient
     long long slab_off[15]; SlabDesc h_slab_desc[15]; SlabDesc* d_slab_desc; int slab_desc_n, slab_desc_cached_n;   // per-layer slab regions; ONE reduce launch per backward pass
-    float *gemm_ws, *col_ws, *fs_scratch, *fs_val;
+    float *gemm_ws, *col_ws, *fs_scratch, *fs_val; size_t gemm_ws_floats;      // split-K / column-sum workspaces: per context
     float* lut;
     unsigned short* lut16;     // uint8 -> bf16(k/255) table (bf16 mode, block1.conv)
     uint8_t* stage_frames; float* stage_obs;
@@ -121,6 +122,7 @@ struct mi_ctx {
     float* h_f; int32_t* h_i; size_t h_f_floats;
     int multirank;
     LossArgs pending; int pending_n;
+    std::string net_err;        // set by the (void) network program on an unsupported launch; every entry point reports it as -4
 };
 
 // ------------------------------------------------------------------------------------------ layout tables
@@ -308,8 +310,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(dalloc(&c->hout, (size_t)NB * (c->A + 1))); HIPC(dalloc(&c->dY, (size_t)NB * (c->A + 1)));
     HIPC(dalloc(&c->d_lp, (size_t)NB * c->A));
     const size_t gws = (size_t)8 << 20;
-    HIPC(dalloc(&c->gemm_ws, gws)); gemm_set_workspace(c->gemm_ws, gws);
-    HIPC(dalloc(&c->col_ws, (size_t)64 * 4096)); colsum_set_workspace(c->col_ws);
+    HIPC(dalloc(&c->gemm_ws, gws)); c->gemm_ws_floats = gws;
+    HIPC(dalloc(&c->col_ws, (size_t)64 * 4096));
     HIPC(dalloc(&c->fs_val, 4));
     HIPC(dalloc(&c->lut, 256));
     {
@@ -329,11 +331,13 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->log_cap = 4096; c->log_count = 0;
     HIPC(dalloc(&c->loss_log, (size_t)c->log_cap * 8));
     HIPC(dalloc(&c->stats_ring, (size_t)c->log_cap * 32)); HIPC(dalloc(&c->fs_ring, (size_t)c->log_cap)); HIPC(dalloc(&c->fs_parts, (size_t)MI_MAX_SEG * 8));
-    HIPC(dalloc(&c->sumsq, 2 + 128)); HIPC(dalloc(&c->gnorm, 2)); sumsq_set_workspace(c->sumsq + 2);
+    HIPC(dalloc(&c->sumsq, 2 + 128)); HIPC(dalloc(&c->gnorm, 2));
     HIPC(dalloc(&c->d_u, (size_t)E));
     HIPC(dalloc(&c->d_pack, (size_t)3 * E)); HIPC(dalloc(&c->d_rd, (size_t)2 * E));
-    HIPC(hipHostMalloc((void**)&c->h_pack, (size_t)3 * E * 4)); HIPC(hipHostMalloc((void**)&c->h_rd, (size_t)2 * E * 4));
-    HIPC(dalloc(&c->d_done_ctr, (size_t)16)); HIPC(hipHostMalloc((void**)&c->h_flag, 64)); *c->h_flag = 0; c->roll_ticket = 0;
+    // written / read by a RUNNING kernel while the host polls the ticket: fine-grained coherent mapping, whatever HIP_HOST_COHERENT says
+    const unsigned hflags = hipHostMallocCoherent | hipHostMallocMapped;
+    HIPC(hipHostMalloc((void**)&c->h_pack, (size_t)3 * E * 4, hflags)); HIPC(hipHostMalloc((void**)&c->h_rd, (size_t)2 * E * 4, hflags));
+    HIPC(dalloc(&c->d_done_ctr, (size_t)16)); HIPC(hipHostMalloc((void**)&c->h_flag, 64, hflags)); *c->h_flag = 0; c->roll_ticket = 0;
     HIPC(dalloc(&c->s_act, (size_t)E)); HIPC(dalloc(&c->s_logp, (size_t)E)); HIPC(dalloc(&c->s_val, (size_t)E)); c->staged_valid = false;
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) {
         HIPC(hipHostMalloc((void**)&c->h_idx_ring[k], (size_t)NB * sizeof(int32_t)));
@@ -394,7 +398,6 @@ int mi_destroy(mi_ctx* c) {
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
     hipHostFree(c->h_f); hipHostFree(c->h_i);
-    gemm_set_workspace(nullptr, 0); sumsq_set_workspace(nullptr);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -596,7 +599,7 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
     a.lut16 = c->bf ? c->lut16 : nullptr;
     const int grid = wgrad_grid_for(L.shape, n, c->bf);
     if (grid < 1) return;
-    if (grid > 1024) { fprintf(stderr, "mi355ppo: wgrad slab workspace too small\n"); abort(); }
+    if (grid > 1024) { c->net_err = "weight-gradient launch needs more than the 1024 slabs a layer owns"; return; }
     const double px = (double)n * L.hw * L.hw;
     { // SURVEY 8(d) layer-boundary bytes; block1.conv from the pooled gradient also carries the max-pool backward (p + 2X)
       const double pool_b = (pool_arg && L.cin == 3) ? c->es * (px / 4 * L.cout + 2.0 * px * L.cout) : 0.0;
@@ -622,6 +625,7 @@ static void conv_wgrad_reduce_all(mi_ctx* c, int n) {
 
 static void linear_fwd(mi_ctx* c, const float* X, int relu_x, const float* W, const float* b, float* Y, int n, int in, int out, int relu_out, int x_bf16 = 0) {
     GemmArgs g{};
+    g.ws = c->gemm_ws; g.ws_floats = c->gemm_ws_floats;
     g.a_bf16 = x_bf16;
     g.A = X; g.B = W; g.C = Y; g.M = n; g.N = out; g.K = in;
     g.sam = in; g.sak = 1; g.sbk = 1; g.sbn = in; g.ldc = out;
@@ -632,6 +636,7 @@ static void linear_fwd(mi_ctx* c, const float* X, int relu_x, const float* W, co
 // dX = dY W  (* mask > 0)
 static void linear_dgrad(mi_ctx* c, const float* dY, const float* W, const float* mask, float* dX, int n, int in, int out, int x_bf16 = 0) {
     GemmArgs g{};
+    g.ws = c->gemm_ws; g.ws_floats = c->gemm_ws_floats;
     g.mask_bf16 = x_bf16; g.c_bf16 = x_bf16;          // mask source and dX are activation-typed
     g.A = dY; g.B = W; g.C = dX; g.M = n; g.N = in; g.K = out;
     g.sam = out; g.sak = 1; g.sbk = in; g.sbn = 1; g.ldc = in; g.mask = mask;
@@ -641,12 +646,13 @@ static void linear_dgrad(mi_ctx* c, const float* dY, const float* W, const float
 // gW += dY^T relu?(X) ; gb += colsum(dY)
 static void linear_wgrad(mi_ctx* c, const float* dY, const float* X, int relu_x, float* gW, float* gb, int n, int in, int out, int x_bf16 = 0) {
     GemmArgs g{};
+    g.ws = c->gemm_ws; g.ws_floats = c->gemm_ws_floats;
     g.b_bf16 = x_bf16;
     g.A = dY; g.B = X; g.C = gW; g.M = out; g.N = in; g.K = n;
     g.sam = 1; g.sak = out; g.sbk = in; g.sbn = 1; g.ldc = in; g.relu_b = relu_x; g.accumulate = 1;
     ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * out + (double)n * in + (double)in * out), 2.0 * n * in * out);
     launch_gemm(g, c->stream);
-    launch_colsum_acc(dY, n, out, out, gb, c->stream);
+    launch_colsum_acc(dY, n, out, out, gb, c->col_ws, c->stream);
 }
 
 static void net_heads(mi_ctx* c, int n) {
@@ -689,7 +695,7 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
                 a.in = prev; a.bias = c->params + L[0].b_off; a.n = n; a.bf16 = 1; a.wbank = c->banks + L[0].bank_f;
                 const double px = (double)n * L[0].hw * L[0].hw;
                 ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, 2.0 * (px * L[0].cin + 2.0 * px * L[0].cout + px / 4 * L[0].cout), px * 18.0 * L[0].cin * L[0].cout);      // 8(d): I + 2X + p
-                if (!launch_conv_pool_fwd_bf16(L[0].shape, a, k.P0, k.PI, c->stream)) { fprintf(stderr, "mi355ppo: no fused conv+pool kernel for this shape\n"); abort(); }
+                if (!launch_conv_pool_fwd_bf16(L[0].shape, a, k.P0, k.PI, c->stream)) { c->net_err = "no fused conv+pool kernel for this conv shape"; return; }
             } else {
             if (b == 0) conv_fwd(c, L[0], nullptr, &src, 0, nullptr, k.C, n);
             else conv_fwd(c, L[0], prev, nullptr, 0, nullptr, k.C, n);
@@ -750,7 +756,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         fc_refresh(c);
         { ProfScope ps(c, PC_GEMM, n, 2.0 * n * 2048 + 4.0 * n * 256 + 4.0 * 2048 * 256, 2.0 * n * 2048 * 256);
           launch_fc_tn(c->dfeat, (const unsigned short*)c->blk[2].P2, c->grads + c->fc.w_off, c->gemm_ws, (size_t)8 << 20, 256, 2048, n, c->stream); }
-        launch_colsum_acc(c->dfeat, n, 256, 256, c->grads + c->fc.b_off, c->stream);
+        launch_colsum_acc(c->dfeat, n, 256, 256, c->grads + c->fc.b_off, c->col_ws, c->stream);
     } else
         linear_wgrad(c, c->dfeat, c->blk[2].P2, 1, c->grads + c->fc.w_off, c->grads + c->fc.b_off, n, 2048, c->H, c->bf);
     float* Gout = c->GP[0];
@@ -870,7 +876,7 @@ int mi_policy_step(mi_ctx* c, int32_t t, uint64_t seed, const float* u, int64_t*
     const bool last = (t == c->T);
     launch_sample(c->hout, E, c->A, du, seed, (unsigned long long)t * E, last ? nullptr : c->act + (size_t)t * E,
                   last ? nullptr : c->logp + (size_t)t * E, c->value + (size_t)t * E, c->stream);
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     if (!act_out && !logp_out && !value_out) { if (u) HIPC(hipStreamSynchronize(c->stream)); return 0; }
     if (act_out && !last) HIPC(hipMemcpyAsync(c->h_i, c->act + (size_t)t * E, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
     if (logp_out && !last) HIPC(hipMemcpyAsync(c->h_f, c->logp + (size_t)t * E, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
@@ -904,7 +910,7 @@ int mi_rollout_step(mi_ctx* c, int32_t t, const float* rew_prev, const float* do
                         last ? nullptr : c->act + (size_t)t * E, last ? nullptr : c->logp + (size_t)t * E, c->value + (size_t)t * E,
                         c->h_pack, nullptr, have_rd ? c->h_rd : nullptr, have_rd ? c->rew + (size_t)(t - 1) * E : nullptr,
                         have_rd ? c->done + (size_t)(t - 1) * E : nullptr, c->stream, c->d_done_ctr, c->h_flag, ++c->roll_ticket);
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     // The last workgroup of the head kernel publishes the ticket after all results (h_pack) are visible to the host and all reads of
     // h_rd / u are done: spinning on it returns ~5 us earlier than hipStreamSynchronize (12.9 -> 8.1 us for launch + wait of a small
     // kernel, scratch/synclat.hip), 257 times per iteration.  A kernel that never finishes (fault) falls back to the stream wait,
@@ -939,7 +945,7 @@ int mi_predict_staged(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, u
     InputSrc src{stage, nullptr, 0};
     net_forward(c, src, E, true);
     launch_sample(c->hout, E, c->A, du, seed, counter, c->s_act, c->s_logp, c->s_val, c->stream);
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     HIPC(hipMemcpyAsync(c->h_i, c->s_act, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipMemcpyAsync(c->h_f, c->s_logp, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipMemcpyAsync(c->h_f + E, c->s_val, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
@@ -989,7 +995,7 @@ int mi_value_saliency(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, u
         linear_dgrad(c, c->sal_src, c->params + c->mlp[0].w_off, nullptr, c->sal_dx, E, c->mlp[0].in, c->mlp[0].out);
     }
     launch_fill(c->grads, c->n_params, 0.f, c->stream);    // discard the parameter gradients of this pass
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     HIPC(hipMemcpyAsync(c->h_i, c->s_act, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipMemcpyAsync(c->h_f, c->s_logp, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipMemcpyAsync(c->h_f + E, c->s_val, (size_t)E * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1062,7 +1068,7 @@ static int forward_common(mi_ctx* c, const void* obs, int32_t n, bool recurrent,
     InputSrc src{stage, nullptr, 0};
     net_forward(c, src, n, recurrent);
     launch_logp_all(c->hout, n, c->A, c->d_lp, nullptr, c->stream);
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     if (logp_all) HIPC(hipMemcpyAsync(logp_all, c->d_lp, (size_t)n * c->A * 4, hipMemcpyDeviceToHost, c->stream));
     if (feat) HIPC(hipMemcpyAsync(feat, c->feat, (size_t)n * c->H * 4, hipMemcpyDeviceToHost, c->stream));
     std::vector<float> h;
@@ -1080,7 +1086,7 @@ int mi_compute_estimates(mi_ctx* c, float gamma, float lmbda, int32_t use_gae, i
         launch_advnorm_stats(c->adv, c->T * c->E, c->adv_stats, c->stream);
         launch_advnorm_apply(c->adv, c->T * c->E, c->adv_stats, c->stream);
     }
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     return 0;
 }
 int mi_adv_stats(mi_ctx* c, double s[3]) {
@@ -1095,7 +1101,7 @@ int mi_adv_apply(mi_ctx* c, const double s[3]) {
     HIPC(hipMemcpyAsync(c->adv_stats, s, 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     launch_advnorm_apply(c->adv, c->T * c->E, c->adv_stats, c->stream);
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     return 0;
 }
 
@@ -1161,7 +1167,7 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
         c->log_count += n_seg;
         if (batch_terms) launch_loss_bwd(a, c->stream);
         net_backward(c, src, n);
-        HIPC(hipGetLastError());
+        HIPC(hipGetLastError()); NETCHK(c);
         return 0;
     }
     // mode 1: the cross-rank sum of the statistics comes between the loss forward and backward (mi_minibatch_finish)
@@ -1169,7 +1175,7 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
     launch_loss_fwd(a, c->stream);
     launch_loss_finalize(a, loss_blocks(n), 1, nullptr, nullptr, c->stream);
     c->pending = a; c->pending_n = n;
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     return 0;
 }
 
@@ -1187,7 +1193,7 @@ int mi_loss_log_finalize(mi_ctx* c) {
     ARG(c, "null"); ARG(c->multirank == 2, "only in multirank mode 2");
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
     launch_loss_finalize_records(c->ring_args, c->log_count, c->stats_ring, impala ? c->fs_ring : nullptr, c->loss_log, c->stream);
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     return 0;
 }
 
@@ -1201,7 +1207,7 @@ int mi_minibatch_finish(mi_ctx* c) {
     InputSrc src = minibatch_src(c);
     net_backward(c, src, c->pending_n);
     c->pending_n = -1;
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     return 0;
 }
 
@@ -1210,11 +1216,11 @@ int mi_optimizer_step(mi_ctx* c, float lr, float max_norm, int32_t step, float* 
     const double b1 = 0.9, b2 = 0.999;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-    launch_sumsq(c->grads, c->n_params, c->sumsq, c->stream);
+    launch_sumsq(c->grads, c->n_params, c->sumsq, c->sumsq + 2, c->stream);
     launch_adam(c->params, c->grads, c->adam_m, c->adam_v, c->n_params, c->sumsq, max_norm, lr, (float)b1, (float)b2, 1e-5f,
                 step_size, bc2_sqrt, c->gnorm, c->stream);
     c->fc_packed_valid = false;
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     if (gnorm_out) {
         HIPC(hipMemcpyAsync(c->h_f, c->gnorm, 4, hipMemcpyDeviceToHost, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
@@ -1315,7 +1321,7 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
             a.wbank = dbank;
             ARG(launch_conv_pool_fwd_bf16(s, a, dp, di, c->stream), "no fused kernel");
         }
-        HIPC(hipGetLastError());
+        HIPC(hipGetLastError()); NETCHK(c);
         HIPC(hipStreamSynchronize(c->stream));
         if (mode == 3) { if (int r = download_act(c, dp, out, pp)) return r; }
         else if (mode == 4) {
@@ -1328,7 +1334,7 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
             const int grid = wgrad_grid_for(s, n, 1);
             launch_conv_wgrad(s, wa, c->stream);
             launch_reduce_slabs(c->slabs, grid, (int)td.n + cout, g, (int)td.n, g + td.n, cout, c->stream);
-            HIPC(hipGetLastError());
+            HIPC(hipGetLastError()); NETCHK(c);
             HIPC(hipStreamSynchronize(c->stream));
             std::vector<float> hg(td.n + cout);
             HIPC(hipMemcpy(hg.data(), g, hg.size() * 4, hipMemcpyDeviceToHost));
@@ -1346,7 +1352,7 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
             if (mode >= 6) { g.wg_in = din; g.wg_partial = c->slabs; HIPC(dalloc(&gw, td.n + cout)); }
             launch_conv_dgrad(s, g, c->stream);
             if (mode >= 6) launch_reduce_slabs(c->slabs, conv_bwd_fused_grid(s, n), (int)td.n + cout, gw, (int)td.n, gw + td.n, cout, c->stream);
-            HIPC(hipGetLastError());
+            HIPC(hipGetLastError()); NETCHK(c);
             HIPC(hipStreamSynchronize(c->stream));
             if (mode == 6) {
                 std::vector<float> hg(td.n + cout);
@@ -1370,7 +1376,7 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
         a.res = dres; a.mask = dmask; a.out = dout_buf; a.lut = c->lut; a.n = n; a.relu_in = (mode == 0) ? relu_in : 0; a.bf16 = c->bf;
         a.lut16 = c->bf ? c->lut16 : nullptr;
         if (mode == 0) launch_conv_fwd(s, a, c->stream); else launch_conv_dgrad(s, a, c->stream);
-        HIPC(hipGetLastError());
+        HIPC(hipGetLastError()); NETCHK(c);
         HIPC(hipStreamSynchronize(c->stream));
         if (int r = download_act(c, dout_buf, out, px * out_ch)) return r;
     } else {
@@ -1383,7 +1389,7 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
         const int grid = wgrad_grid_for(s, n, c->bf);
         launch_conv_wgrad(s, a, c->stream);
         launch_reduce_slabs(c->slabs, grid, (int)td.n + cout, g, (int)td.n, g + td.n, cout, c->stream);
-        HIPC(hipGetLastError());
+        HIPC(hipGetLastError()); NETCHK(c);
         HIPC(hipStreamSynchronize(c->stream));
         std::vector<float> hg(td.n + cout);
         HIPC(hipMemcpy(hg.data(), g, hg.size() * 4, hipMemcpyDeviceToHost));
@@ -1435,7 +1441,7 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
         else launch_resblock_bwd_full32_bf16(s, dx, da, dxf, doy, nullptr, n, dbanks, dbanks + bl, sl2, sl1, c->stream);
         launch_reduce_slabs(sl1, grid, slab, g, (int)wl, g + wl, ch, c->stream);
         launch_reduce_slabs(sl2, grid, slab, g + slab, (int)wl, g + slab + wl, ch, c->stream);
-        HIPC(hipGetLastError());
+        HIPC(hipGetLastError()); NETCHK(c);
         HIPC(hipStreamSynchronize(c->stream));
         std::vector<float> hg(2 * slab);
         HIPC(hipMemcpy(hg.data(), g, hg.size() * 4, hipMemcpyDeviceToHost));
@@ -1457,7 +1463,7 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
         if (int r = upload_act(c, x_fwd, X, &dxf)) return r;
         launch_resblock_bwd_bf16(s, dx, da, dxf, doa, doy, n, dbanks, dbanks + bl, c->stream);
     }
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     HIPC(hipStreamSynchronize(c->stream));
     if (int r = download_act(c, doa, out_a, X)) return r;
     if (int r = download_act(c, doy, out_y, X)) return r;
@@ -1467,7 +1473,8 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
 }
 
 int mi_op_maxpool(mi_ctx* c, int32_t mode, int32_t n, int32_t hw, int32_t ch, const float* in, const float* dout, float* out) {
-    ARG(c && in && out, "null");
+    ARG(c && in && out, "null"); ARG(n >= 1, "n");
+    ARG((hw == 64 && ch == 16) || (hw == 32 && ch == 32) || (hw == 16 && ch == 32), "max pool shapes of the IMPALA blocks only: (64,16), (32,32), (16,32)");
     const size_t X = (size_t)n * hw * hw * ch, p = X / 4;
     void *din = nullptr, *dp = nullptr, *dd = nullptr, *dg = nullptr; uint8_t* di = nullptr;
     if (int r = upload_act(c, in, X, &din)) return r;
@@ -1482,7 +1489,7 @@ int mi_op_maxpool(mi_ctx* c, int32_t mode, int32_t n, int32_t hw, int32_t ch, co
         HIPC(hipStreamSynchronize(c->stream));
         if (int r = download_act(c, dg, out, X)) return r;
     }
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     hipFree(din); hipFree(dp); hipFree(di); if (dd) hipFree(dd); if (dg) hipFree(dg);
     return 0;
 }
@@ -1495,9 +1502,10 @@ int mi_op_gemm(mi_ctx* c, int32_t M, int32_t N, int32_t K, const float* A, int64
     HIPC(dalloc(&da, na)); HIPC(dalloc(&db, nb)); HIPC(dalloc(&dc, (size_t)M * N));
     HIPC(hipMemcpy(da, A, na * 4, hipMemcpyHostToDevice)); HIPC(hipMemcpy(db, B, nb * 4, hipMemcpyHostToDevice));
     GemmArgs g{};
+    g.ws = c->gemm_ws; g.ws_floats = c->gemm_ws_floats;
     g.A = da; g.B = db; g.C = dc; g.M = M; g.N = N; g.K = K; g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = N;
     launch_gemm(g, c->stream);
-    HIPC(hipGetLastError());
+    HIPC(hipGetLastError()); NETCHK(c);
     HIPC(hipStreamSynchronize(c->stream));
     HIPC(hipMemcpy(C, dc, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     hipFree(da); hipFree(db); hipFree(dc);

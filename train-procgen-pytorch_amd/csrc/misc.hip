@@ -149,31 +149,28 @@ __global__ void gemm_splitk_reduce(const float* ws, int split, GemmArgs g) {
     g.C[o] = v;
 }
 
-static float* g_gemm_ws = nullptr;
-static size_t g_gemm_ws_floats = 0;
-void gemm_set_workspace(float* ws, size_t floats) { g_gemm_ws = ws; g_gemm_ws_floats = floats; }
-
+// split-K slabs live in the caller's workspace (GemmArgs.ws, one per context: two contexts on two streams must not share it)
 void launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return;
     const int tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
     int split = 1;
     // few output tiles and a long K (weight gradients: K = batch; rollout-sized forward GEMMs: M = n_envs):
     // split K over workgroups, slabs summed in a fixed order by the reduce kernel (which carries the epilogue).
-    if (g.K >= 512 && tm * tn < 192 && g_gemm_ws) {
+    if (g.K >= 512 && tm * tn < 192 && g.ws) {
         split = 512 / (tm * tn);
         if (split > g.K / 128) split = g.K / 128;
         if (split < 1) split = 1;
-        while (split > 1 && (size_t)split * g.M * g.N > g_gemm_ws_floats) --split;
+        while (split > 1 && (size_t)split * g.M * g.N > g.ws_floats) --split;
     }
     int k_chunk = ((g.K + split - 1) / split + 31) / 32 * 32;
     if (split == 1) {
         hipLaunchKernelGGL(gemm_kernel, dim3(tn, tm, 1), dim3(256), 0, st, g, k_chunk, (float*)nullptr);
     } else {
         split = (g.K + k_chunk - 1) / k_chunk;
-        hipLaunchKernelGGL(gemm_kernel, dim3(tn, tm, split), dim3(256), 0, st, g, k_chunk, g_gemm_ws);
+        hipLaunchKernelGGL(gemm_kernel, dim3(tn, tm, split), dim3(256), 0, st, g, k_chunk, g.ws);
         const long long tot = (long long)g.M * g.N;
         hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
-                           (const float*)g_gemm_ws, split, g);
+                           (const float*)g.ws, split, g);
     }
 }
 
@@ -432,13 +429,11 @@ __global__ void colsum_partial_kernel(const float* dY, int M, int N, int ld, flo
         part[(long long)rg * N + n] = s;
     }
 }
-static float* g_col_ws = nullptr;
-void colsum_set_workspace(float* ws) { g_col_ws = ws; }
-void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, hipStream_t st) {
+void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, float* col_ws, hipStream_t st) {
     if (M <= 0) return;
     const int gy = (M >= 4096 && N <= 1024) ? 64 : 16;         // workspace: 64 x 4096 floats (engine.hip)
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, st, dY, M, N, ld, g_col_ws);
-    launch_reduce_slabs(g_col_ws, gy * 4, N, db, N, nullptr, 0, st);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, st, dY, M, N, ld, col_ws);
+    launch_reduce_slabs(col_ws, gy * 4, N, db, N, nullptr, 0, st);
 }
 
 __global__ void gather_rows_kernel(const float* src, const int32_t* idx, long long base, float* dst, int n, int d) {
@@ -1127,12 +1122,10 @@ __global__ void sumsq_final_kernel(const double* part, int n, double* out) {    
     t = wave_sum(t);
     if (threadIdx.x == 0) out[0] = t;
 }
-static double* g_sumsq_part = nullptr;
-void sumsq_set_workspace(double* ws) { g_sumsq_part = ws; }      // >= 128 doubles
-void launch_sumsq(const float* g, long long n, double* out, hipStream_t st) {
-    if (!g_sumsq_part) { hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, st, g, n, out); return; }
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(128), dim3(256), 0, st, g, n, g_sumsq_part);
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, (const double*)g_sumsq_part, 128, out);
+void launch_sumsq(const float* g, long long n, double* out, double* part /* >= 128 doubles, or null */, hipStream_t st) {
+    if (!part) { hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, st, g, n, out); return; }
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(128), dim3(256), 0, st, g, n, part);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, (const double*)part, 128, out);
 }
 __global__ void adam_kernel(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr_unused,
                             float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float* gnorm_out) {
