@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: env steps/sec of the PPO hot path, coinrun hard-500 shape (IMPALA-CNN, T=256,
-256 envs per GPU, 3 epochs x 8 minibatches of 8192), learner side, synthetic frames resident in HBM.
+256 envs per GPU, 3 epochs x 8 minibatches of 8192), learner side, synthetic frames in pinned host memory.
 
-One "step" (--steps) = one PPO iteration = T*E env steps: T+1 policy steps on the stored frames (forward,
-sample, actions read back to the host every step, rewards/dones uploaded every step), GAE + advantage
-normalisation, then epoch x n_minibatch minibatch updates (index gather inside the first conv, forward,
-fused loss, backward, clip + Adam) -- everything agents/ppo.py:225-255 does except env.step and logging.
+One "step" (--steps) = one PPO iteration = T*E env steps: T+1 policy steps, each one uploading its E uint8
+frames from pinned host memory (H2D inside the timed region), forward, sample, actions read back to the host,
+rewards/dones uploaded; GAE + advantage normalisation; then epoch x n_minibatch minibatch updates (index gather
+inside the first conv, forward, fused loss, backward, clip + Adam) -- everything agents/ppo.py:225-255 does
+except env.step and logging ("rollout inference + H2D + GAE + epoch passes of minibatch updates").
 
     python bench.py                      # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -167,7 +168,10 @@ def main():
                     "(minibatches of mini_batch_size/R, R-fold gradient accumulation, no collectives)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="diagnostic: run the N-rank code path (sharding, merged accumulation, "
                     "gradient / statistics all-reduce, barriers) with every rank on GPU 0 and the gloo backend; the number it prints is not a result")
-    ap.add_argument("--h2d", action="store_true", help="also upload the E frames of every rollout step from pinned host memory")
+    ap.add_argument("--no-h2d", action="store_true", help="diagnostic: policy steps read frames already resident in HBM (no per-step upload); "
+                    "the default uploads every step's E frames from pinned host memory inside the timed region, as the real loop must")
+    ap.add_argument("--rollout-groups", type=int, default=2, help="env groups of the pipelined rollout (1 = the reference's serial step: "
+                    "upload, forward, read-back one after the other)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -219,22 +223,36 @@ def main():
         stage[...] = rng.integers(0, 256, size=stage.shape, dtype=np.uint8)
         eng.put_obs(t, stage)
         eng.sync()
-    if args.h2d:
-        host_frames = [eng.pinned((E, 64, 64, 3), np.uint8) for _ in range(4)]
-        for h in host_frames:
-            h[...] = rng.integers(0, 256, size=h.shape, dtype=np.uint8)
+    G = max(1, args.rollout_groups)
+    if E % G:
+        raise SystemExit(f"--rollout-groups {G} does not divide n_envs={E}")
+    ng = E // G
+    eng.rollout_groups(G)
+    if not args.no_h2d:
+        # what Procgen's rgb buffer would hand over: per env group a small ring of pinned (E/G,64,64,3) uint8 buffers
+        host_frames = [[eng.pinned((ng, 64, 64, 3), np.uint8) for _ in range(4)] for _ in range(G)]
+        for hg in host_frames:
+            for h in hg:
+                h[...] = rng.integers(0, 256, size=h.shape, dtype=np.uint8)
 
     phase = {"rollout_s": 0.0}
 
     def iteration(it):
         t_r = time.perf_counter()
-        for t in range(T + 1):                          # T policy steps + the bootstrap-value step
-            if host_frames is not None:
-                eng.put_obs(t, host_frames[t & 3])
-            # act/logp/value come back to the host every step (env.step needs act); the previous step's
-            # reward / done (what env.step returned) go up with the same call
-            eng.rollout_step(t, rew[t - 1] if t else None, done[t - 1] if t else None, seed=it)
-        phase["rollout_s"] += time.perf_counter() - t_r         # every rollout_step ends with its read-back: no extra sync
+        # T policy steps + the bootstrap-value step.  Per env group g the real loop's dependency chain is kept: the frames of step t
+        # go up only AFTER the group's actions of step t-1 have reached the host (rollout_wait; env.step(act) would run right there),
+        # and with them the reward / done that env.step returned.  Groups are independent chains: while the host waits for group g,
+        # the other groups' uploads and forward passes are in flight on their own streams.
+        for t in range(T + 1):
+            for g in range(G):
+                if t:
+                    eng.rollout_wait(g)
+                sl = slice(g * ng, (g + 1) * ng)
+                eng.rollout_submit(t, g, None if host_frames is None else host_frames[g][t & 3],
+                                   rew[t - 1, sl] if t else None, done[t - 1, sl] if t else None, seed=it)
+        for g in range(G):
+            eng.rollout_wait(g)
+        phase["rollout_s"] += time.perf_counter() - t_r         # every group's last step has been read back: no extra sync
         storage.compute_estimates(hp["gamma"], hp["lmbda"], hp["use_gae"], hp["normalize_adv"], agent.coll)
         return agent.optimize()
 
@@ -293,7 +311,9 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if args.precision == "bf16" else "f32"), "data": "synthetic" + (" -- REHEARSAL: every rank on GPU 0, gloo; not a result" if args.rehearse_on_one_gpu else ""),
                "config": {"workload": f"PPO iteration, {args.param_name}: IMPALA-CNN, T={T}, E={E} envs per GPU, "
                                       f"{hp['epoch']} epochs x {hp['n_minibatch']} minibatches of {agent.mini_batch_size} (global), "
-                                      f"A={A}, frames resident in HBM" + (" + per-step H2D" if args.h2d else ""),
+                                      f"A={A} (--no-reduce_duplicate_actions; the reference default merges them to 9), "
+                                      + (f"every policy step uploads its E frames from pinned host memory (pipelined over {G} env groups)" if host_frames is not None
+                                         else "DIAGNOSTIC --no-h2d: frames resident in HBM, no per-step upload"),
                           "parallelism": f"dp{world} over n_envs"},
                "roofline": roof,
                # SURVEY 8(d), whole path: env steps/s per GPU x (B_step, F_step) of the layer-boundary model against the HBM / matrix peaks

@@ -90,6 +90,21 @@ int mi_policy_step(mi_ctx* ctx, int32_t t, uint64_t seed, const float* u,
 int mi_rollout_step(mi_ctx* ctx, int32_t t, const float* rew_prev, const float* done_prev, uint64_t seed, const float* u,
                     int64_t* act_out, float* logp_out, float* value_out);
 
+/* ---- pipelined rollout: the same step as mi_rollout_step, per ENV GROUP and split into submit / wait, so that the frame upload and
+ *      forward pass of one group run beside the host's env.step of another (agents/ppo.py:225-231 is strictly serial; an env's next
+ *      observation depends on its own action only, so G contiguous groups of E/G envs form G independent chains).
+ *      mi_rollout_groups(G) (1 <= G <= 4, E % G == 0) creates a stream per group.  mi_rollout_submit(t, g, frames, ...) enqueues on
+ *      group g's stream: the H2D copy of the group's E/G observations (frames: pinned host memory from mi_host_alloc, valid until the
+ *      matching wait; NULL = ring slot t already holds them) into ring slot t, the forward + sample on them, and the store of the
+ *      previous step's reward / done of the group (rew_prev / done_prev: E/G floats each, may be NULL at t == 0); it returns at once.
+ *      mi_rollout_wait(g, ...) blocks until that step's results (E/G entries each) are on the host.  One step per group in flight.
+ *      Sampling uses the Philox counters t*E + e of mi_rollout_step: grouped and ungrouped rollouts draw the same actions.
+ *      Any other entry point first orders the context's main stream behind all group streams. */
+int mi_rollout_groups(mi_ctx* ctx, int32_t n_groups);
+int mi_rollout_submit(mi_ctx* ctx, int32_t t, int32_t group, const void* frames, size_t bytes, const float* rew_prev,
+                      const float* done_prev, uint64_t seed, const float* u);
+int mi_rollout_wait(mi_ctx* ctx, int32_t group, int64_t* act_out, float* logp_out, float* value_out);
+
 /* ---- PPO.predict(obs, hidden, done) on caller data (agents/ppo.py:72-81) when the caller has not said which
  *      storage slot the observation belongs to: obs (E frames / rows) is staged on the device, forward + sample
  *      run on it, and mi_commit_staged(t) later moves the staged observation and policy outputs into ring slot t

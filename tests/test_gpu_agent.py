@@ -86,6 +86,40 @@ def test_public_predict_store_path_equals_fast_path():
     np.testing.assert_array_equal(sal, sal_u8.transpose(0, 3, 1, 2))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pipelined_collect_equals_serial_collect(precision):
+    """PPO._collect over an env with `.env_groups` (two independent sub-envs: upload + forward of one group beside the host's
+    env.step of the other) fills the device ring and the host mirrors exactly like the reference-shaped serial loop over the same
+    sub-envs stepped as one VecEnv."""
+    from common.env.vec_envs import EnvGroups, SyntheticFrames
+    from mi355 import engine as M
+    T, E = 5, 16
+
+    class Serial:                                            # the same env without the group attribute: forces the serial path
+        def __init__(self, env):
+            self._e = env
+            self.observation_space, self.action_space = env.observation_space, env.action_space
+        reset = lambda self: self._e.reset()
+        step = lambda self, a: self._e.step(a)
+
+    res = []
+    for pipelined in (False, True):
+        agent, policy, storage = _impala_agent(T, E, 16, precision=precision)
+        env = EnvGroups([SyntheticFrames(E // 2, 15, seed=11), SyntheticFrames(E // 2, 15, seed=12)])
+        if not pipelined:
+            env = Serial(env)
+        obs, hid, done = agent._collect(env, agent.engine, storage, env.reset(), np.zeros((E, 256), np.float32), np.zeros(E, np.float32))
+        eng = agent.engine
+        storage.compute_estimates(0.999, 0.95, True, True)
+        rb, db, _ = storage.fetch_log_data()
+        res.append(dict(obs=np.stack([eng.get_obs(t) for t in range(T + 1)]), act=eng.read_field(M.F_ACT), logp=eng.read_field(M.F_LOGP),
+                        val=eng.read_field(M.F_VALUE), rew=eng.read_field(M.F_REW), done=eng.read_field(M.F_DONE), adv=eng.read_field(M.F_ADV),
+                        host_rew=np.asarray(rb, np.float64), host_done=np.asarray(db, np.float64), last_obs=np.asarray(obs), step=storage.step))
+        assert getattr(eng, "n_groups", 1) == (2 if pipelined else 1)
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     """torch.save({'model_state_dict','optimizer_state_dict'}) (agents/ppo.py:271-276) loads into plain torch
     objects with the reference's key names, and back into a fresh agent bit-exactly (train.py:257-263)."""

@@ -357,6 +357,70 @@ def test_policy_step_sampling():
     eng.close()
 
 
+@pytest.mark.parametrize("arch,precision,groups", [("impala", "bf16", 2), ("impala", "fp32", 4), ("mlp", "fp32", 2)])
+def test_pipelined_rollout_groups_equal_serial_steps(arch, precision, groups):
+    """mi_rollout_submit / mi_rollout_wait over G env groups (own streams, own rows of the activation buffers, frames uploaded by the
+    submit) leave the ring and return the numbers of the serial mi_put_obs + mi_rollout_step loop: bit-equal actions / log-probs /
+    values / rewards / dones / frames (same kernels on the same rows; Philox counters t*E + e in both)."""
+    from mi355 import engine as M, layout
+    from mi355.engine import Engine
+    T, E, A = 3, 32, (15 if arch == "impala" else 2)
+    rng = np.random.default_rng(17)
+    params = dict(golden_params(arch))
+    params["fc_policy.weight"] = params["fc_policy.weight"] * 200.0
+    flat = layout.flatten(shapes_for(arch, A), params)
+    if arch == "impala":
+        obs = rng.integers(0, 256, size=(T + 1, E, 64, 64, 3), dtype=np.uint8)
+        mk = lambda: Engine("impala", T, E, A, E, precision=precision)
+    else:
+        obs = rng.standard_normal((T + 1, E, 9)).astype(np.float32)
+        mk = lambda: Engine("mlp", T, E, A, E, obs_dim=9, mlp_depth=4, mlp_width=256, out_dim=64)
+    rew = rng.standard_normal((T, E)).astype(np.float32); done = (rng.random((T, E)) < 0.3).astype(np.float32)
+
+    def readout(eng, outs):
+        r = dict(act=np.stack([o[0] for o in outs[:T]]), logp=np.stack([o[1] for o in outs[:T]]), val=np.stack([o[2] for o in outs]),
+                 f_act=eng.read_field(M.F_ACT), f_logp=eng.read_field(M.F_LOGP), f_val=eng.read_field(M.F_VALUE),
+                 f_rew=eng.read_field(M.F_REW), f_done=eng.read_field(M.F_DONE), obs=np.stack([eng.get_obs(t) for t in range(T + 1)]))
+        eng.compute_estimates(0.999, 0.95, True, True)
+        r["adv"] = eng.read_field(M.F_ADV)
+        return r
+
+    ser = mk(); ser.set_params(flat)
+    outs = []
+    for t in range(T + 1):
+        ser.put_obs(t, obs[t])
+        outs.append(ser.rollout_step(t, rew[t - 1] if t else None, done[t - 1] if t else None, seed=5))
+    a = readout(ser, outs); ser.close()
+
+    pip = mk(); pip.set_params(flat)
+    pip.rollout_groups(groups)
+    ng = E // groups
+    stage = [[pip.pinned(obs[0, :ng].shape, obs.dtype) for _ in range(2)] for _ in range(groups)]
+    outs = []
+    for t in range(T + 1):
+        for g in range(groups):
+            if t:
+                got[g] = pip.rollout_wait(g)
+            else:
+                got = [None] * groups
+            sl = slice(g * ng, (g + 1) * ng)
+            stage[g][t & 1][...] = obs[t, sl]
+            pip.rollout_submit(t, g, stage[g][t & 1], np.ascontiguousarray(rew[t - 1, sl]) if t else None,
+                               np.ascontiguousarray(done[t - 1, sl]) if t else None, seed=5)
+            if t and g == groups - 1:
+                outs.append(tuple(np.concatenate([x[j] for x in got]) for j in range(3)))
+    got = [pip.rollout_wait(g) for g in range(groups)]
+    outs.append(tuple(np.concatenate([x[j] for x in got]) for j in range(3)))
+    b = readout(pip, outs)
+    # a main-stream call after group work (here: the read-backs above) re-joins; a further grouped step then forks again
+    pip.rollout_submit(0, 0, None, seed=5); again = pip.rollout_wait(0)
+    assert np.array_equal(again[0], a["act"][0, :ng]) and np.array_equal(again[2], a["val"][0, :ng])
+    pip.close()
+    assert len(set(a["act"].reshape(-1).tolist())) > 1
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_contexts_do_not_share_workspaces():
     """Two contexts live at once (PPO builds a training and a validation engine), the second destroyed first: the survivor's
     minibatch + optimizer step must be bit-equal to a run where it was alone.  (Split-K, column-sum and grad-norm workspaces were

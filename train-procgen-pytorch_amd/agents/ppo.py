@@ -93,6 +93,7 @@ class PPO(BaseAgent):
             self._ring_t = DevicePointerTensor(rp, rn).tensor(dev_index)
         self._stage = [self.engine.pinned((n_envs,) + self._obs_stage_shape(arch, emb), self._obs_dtype(arch)) for _ in range(2)]
         self._stage_i = 0
+        self._gstage = {}
         self._iter = 0
 
     @staticmethod
@@ -213,6 +214,8 @@ class PPO(BaseAgent):
 
     # ------------------------------------------------------------------ rollout + train
     def _collect(self, env, engine, storage, obs, hidden_state, done):
+        if len(getattr(env, "env_groups", ())) > 1 and not self.policy.is_recurrent() and self.n_envs % len(env.env_groups) == 0:
+            return self._collect_pipelined(env, engine, storage, obs, hidden_state, done)
         for _ in range(self.n_steps):
             t = storage.step
             act, logp, value, next_hidden = self._predict_into(engine, storage, t, obs, hidden_state, done)
@@ -222,6 +225,41 @@ class PPO(BaseAgent):
         _, _, last_val, hidden_state = self._predict_into(engine, storage, self.n_steps, obs, hidden_state, done)
         storage.store_last(obs, hidden_state, last_val)
         return obs, hidden_state, done
+
+    def _collect_pipelined(self, env, engine, storage, obs, hidden_state, done):
+        """The same T steps + bootstrap step with the env groups of `env.env_groups` as independent chains (mi_rollout_submit /
+        mi_rollout_wait): while the host waits for / steps group g, the other groups' frame uploads and forward passes run on
+        their own streams.  Device ring and returned arrays are those of `_collect` (same kernels, same sampling counters)."""
+        groups = env.env_groups
+        G, E, T = len(groups), self.n_envs, self.n_steps
+        ng = E // G
+        key = id(engine)
+        if getattr(engine, "n_groups", 1) != G:
+            engine.rollout_groups(G)
+        st = self._gstage.setdefault(key, [[engine.pinned((ng,) + self._obs_stage_shape(self.policy.arch, self.policy.embedder),
+                                                          self._obs_dtype(self.policy.arch)) for _ in range(2)] for _ in range(G)])
+        obs_g = [obs[g * ng:(g + 1) * ng] for g in range(G)]
+        rew = np.zeros(E, np.float32); dn = np.zeros(E, np.float32)
+        act = np.zeros(E, np.int64); logp = np.zeros(E, np.float32); val = np.zeros(E, np.float32)
+        infos = [None] * G
+        seed = self.seed * 1000003 + self._iter
+        for t in range(T + 1):
+            for g in range(G):
+                sl = slice(g * ng, (g + 1) * ng)
+                if t:
+                    act[sl], logp[sl], val[sl] = engine.rollout_wait(g)
+                    obs_g[g], r, d, infos[g] = groups[g].step(act[sl])
+                    rew[sl] = r; dn[sl] = d
+                buf = st[g][t & 1]
+                buf[...] = as_device_obs(obs_g[g], self.policy.arch)
+                engine.rollout_submit(t, g, buf, rew[sl] if t else None, dn[sl] if t else None, seed=seed)
+            if t:
+                storage.note_stored(rew, dn, [i for x in infos for i in x], hidden_state)
+        for g in range(G):
+            engine.rollout_wait(g)
+        obs = np.concatenate(obs_g)
+        storage._hidden[T] = hidden_state                    # store_last: value[T] and the frames are already in the device ring
+        return obs, hidden_state, dn.copy()
 
     def train(self, num_timesteps):
         self.total_timesteps = num_timesteps

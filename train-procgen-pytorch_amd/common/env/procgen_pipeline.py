@@ -72,8 +72,8 @@ class RewardNormalizer:
     """VecNormalize(ob=False) (procgen_wrappers.py:316-355): rewards divided by the running std of the discounted return
     (gamma 0.99), clipped to +-10; the discounted return of an env restarts after its episode ends."""
 
-    def __init__(self, n_envs, cliprew=10.0, gamma=0.99, epsilon=1e-8):
-        self.ret_rms = RunningMoments()
+    def __init__(self, n_envs, cliprew=10.0, gamma=0.99, epsilon=1e-8, ret_rms=None):
+        self.ret_rms = ret_rms if ret_rms is not None else RunningMoments()      # env groups of one run share ONE running variance
         self.ret = np.zeros(n_envs)
         self.cliprew, self.gamma, self.epsilon = cliprew, gamma, epsilon
 
@@ -101,7 +101,7 @@ class _Space:
 
 
 class ProcgenFrameSource:
-    def __init__(self, venv, normalize_rew=True, mirror_env=False, reduce_duplicate_actions=True, key="rgb"):
+    def __init__(self, venv, normalize_rew=True, mirror_env=False, reduce_duplicate_actions=True, key="rgb", ret_rms=None):
         self.venv = venv
         self.num_envs = self.n_envs = venv.num_envs
         self.key = key
@@ -115,7 +115,7 @@ class ProcgenFrameSource:
         self._mirror = mirror_action_table(combos) if mirror_env else None
         self._flip = (np.arange(self.num_envs) % 2 == 1)                    # odd envs are mirrored (procgen_wrappers.py:374)
         self._flipped = None
-        self._rew = RewardNormalizer(self.num_envs) if normalize_rew else None
+        self._rew = RewardNormalizer(self.num_envs, ret_rms=ret_rms) if normalize_rew else None
         self._act_dtype = getattr(getattr(venv, "action_space", None), "dtype", None) or np.int32
         self.observation_space = _Space(shape=(3, 64, 64))                  # what TransposeFrame advertises; the DATA stays NHWC uint8
         self.action_space = _Space(n=n_actions)
@@ -180,7 +180,7 @@ def _find_combos(env):
 
 def create_procgen_env(env_name="coinrun", n_envs=256, is_valid=False, val_env_name=None, start_level=0, num_levels=500,
                        distribution_mode="hard", num_threads=8, paint_vel_info=True, normalize_rew=True, mirror_env=False,
-                       reduce_duplicate_actions=True, start_level_val=None):
+                       reduce_duplicate_actions=True, start_level_val=None, ret_rms=None):
     """procgen_wrappers.py:524-587 for the real-Procgen branch: the validation env draws from all levels (`num_levels=0`)
     starting at a random level in [500, 9999]."""
     try:
@@ -197,4 +197,4 @@ def create_procgen_env(env_name="coinrun", n_envs=256, is_valid=False, val_env_n
                       num_levels=0 if is_valid else num_levels, start_level=start_level_val if is_valid else start_level,
                       paint_vel_info=paint_vel_info, distribution_mode=distribution_mode, num_threads=num_threads)
     return ProcgenFrameSource(venv, normalize_rew=normalize_rew, mirror_env=mirror_env,
-                              reduce_duplicate_actions=reduce_duplicate_actions)
+                              reduce_duplicate_actions=reduce_duplicate_actions, ret_rms=ret_rms)

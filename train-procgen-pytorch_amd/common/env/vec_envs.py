@@ -86,6 +86,41 @@ class SyntheticFrames:
         pass
 
 
+class EnvGroups:
+    """G independent vector envs shown as ONE VecEnv of sum(n_envs) environments (reset / step concatenate in group order), plus
+    `.env_groups` for the agent's pipelined collector (agents/ppo.py `_collect_pipelined`): an env's next observation depends only
+    on its own action, so the agent steps group g on the host while the device works on the other groups' frames."""
+
+    def __init__(self, envs):
+        self.env_groups = list(envs)
+        e0 = self.env_groups[0]
+        self.n_envs = self.num_envs = sum(getattr(e, "n_envs", getattr(e, "num_envs", 0)) for e in self.env_groups)
+        self.observation_space, self.action_space = e0.observation_space, e0.action_space
+        for k in ("combos", "unique_actions"):
+            if hasattr(e0, k):
+                setattr(self, k, getattr(e0, k))
+
+    def reset(self):
+        return np.concatenate([e.reset() for e in self.env_groups])
+
+    def step(self, act):
+        act = np.asarray(act)
+        outs, o = [], 0
+        for e in self.env_groups:
+            n = getattr(e, "n_envs", getattr(e, "num_envs", 0))
+            outs.append(e.step(act[o:o + n])); o += n
+        return (np.concatenate([x[0] for x in outs]), np.concatenate([x[1] for x in outs]), np.concatenate([x[2] for x in outs]),
+                [i for x in outs for i in x[3]])
+
+    def reward_state(self):
+        rs = getattr(self.env_groups[0], "reward_state", None)
+        return rs() if callable(rs) else None
+
+    def close(self):
+        for e in self.env_groups:
+            e.close()
+
+
 def create_procgen_env(**kwargs):
     """The Procgen engine behind the one-object wrapper chain of common/env/procgen_pipeline.py (uint8 NHWC frames out)."""
     from common.env.procgen_pipeline import create_procgen_env as make

@@ -89,6 +89,19 @@ class Storage:
         self._pending = None
         self.step = (self.step + 1) % self.num_steps
 
+    def note_stored(self, rew, done, info, hidden_state=None):
+        """Host half of store() for the pipelined collector: the device ring already holds this step's frames (uploaded by
+        mi_rollout_submit), policy outputs (written by the step's kernels) and reward / done (handed over with the next submit); only
+        the host mirrors that Logger / fetch_log_data read are filled in."""
+        t = self.step
+        self._rew[t] = rew
+        self._done[t] = done
+        if hidden_state is not None:
+            self._hidden[t] = hidden_state
+        self.info_batch.append(info)
+        self._pending = None
+        self.step = (self.step + 1) % self.num_steps
+
     def store_last(self, last_obs, last_hidden_state, last_value):
         eng, T = self._eng(), self.num_steps
         pend = self._pending if self._claim(T, last_obs) else None

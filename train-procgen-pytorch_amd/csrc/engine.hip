@@ -30,6 +30,11 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define ARG(c, msg) do { if (!(c)) return fail(-1, std::string("invalid argument: ") + msg); } while (0)
 #define NETCHK(c) do { if (!(c)->net_err.empty()) { std::string m_ = (c)->net_err; (c)->net_err.clear(); return fail(-4, m_); } } while (0)
 
+struct mi_ctx;
+static int join_groups(mi_ctx* c);
+// every entry point that issues work on the context's main stream first orders it behind the env-group streams of a pipelined rollout
+#define JOIN(c) do { if ((c)->groups_live) { int r_ = join_groups(c); if (r_) return r_; } } while (0)
+
 enum TKind { K_PLAIN = 0, K_CONVW, K_FCW };
 struct TensorDesc {
     std::string name;
@@ -122,6 +127,11 @@ struct mi_ctx {
     float* h_f; int32_t* h_i; size_t h_f_floats;
     int multirank;
     LossArgs pending; int pending_n;
+    // pipelined rollout (mi_rollout_submit / mi_rollout_wait): contiguous env groups, each on its own stream with its own rows of the
+    // activation buffers, so that one group's frame upload + forward runs beside the host's wait for another group's actions
+    static constexpr int MAX_GROUPS = 4;
+    int n_groups; hipStream_t main_stream, gs[MAX_GROUPS]; hipEvent_t ev_fork[MAX_GROUPS], ev_join[MAX_GROUPS];
+    bool g_forked[MAX_GROUPS], g_busy[MAX_GROUPS], g_last[MAX_GROUPS], g_dirty[MAX_GROUPS]; unsigned g_ticket[MAX_GROUPS]; bool groups_live;
     std::string net_err;        // set by the (void) network program on an unsupported launch; every entry point reports it as -4
 };
 
@@ -212,7 +222,7 @@ static void to_ref_layout(const TensorDesc& t, const float* dev, float* ref) {
 }
 
 static int upload_flat(mi_ctx* c, float* dbuf, const float* flat, int64_t n) {
-    ARG(n == c->n_params, "flat vector length != mi_param_count");
+    ARG(n == c->n_params, "flat vector length != mi_param_count"); JOIN(c);
     std::vector<float> tmp(n);
     for (auto& t : c->tensors) to_device_layout(t, flat + t.ref_off, tmp.data() + t.dev_off);
     HIPC(hipMemcpyAsync(dbuf, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -220,7 +230,7 @@ static int upload_flat(mi_ctx* c, float* dbuf, const float* flat, int64_t n) {
     return 0;
 }
 static int download_flat(mi_ctx* c, const float* dbuf, float* flat, int64_t n) {
-    ARG(n == c->n_params, "flat vector length != mi_param_count");
+    ARG(n == c->n_params, "flat vector length != mi_param_count"); JOIN(c);
     std::vector<float> tmp(n);
     HIPC(hipMemcpyAsync(tmp.data(), dbuf, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
@@ -337,7 +347,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     // written / read by a RUNNING kernel while the host polls the ticket: fine-grained coherent mapping, whatever HIP_HOST_COHERENT says
     const unsigned hflags = hipHostMallocCoherent | hipHostMallocMapped;
     HIPC(hipHostMalloc((void**)&c->h_pack, (size_t)3 * E * 4, hflags)); HIPC(hipHostMalloc((void**)&c->h_rd, (size_t)2 * E * 4, hflags));
-    HIPC(dalloc(&c->d_done_ctr, (size_t)16)); HIPC(hipHostMalloc((void**)&c->h_flag, 64, hflags)); *c->h_flag = 0; c->roll_ticket = 0;
+    HIPC(dalloc(&c->d_done_ctr, (size_t)16)); HIPC(hipHostMalloc((void**)&c->h_flag, 64, hflags)); memset(c->h_flag, 0, 64); c->roll_ticket = 0;
     HIPC(dalloc(&c->s_act, (size_t)E)); HIPC(dalloc(&c->s_logp, (size_t)E)); HIPC(dalloc(&c->s_val, (size_t)E)); c->staged_valid = false;
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) {
         HIPC(hipHostMalloc((void**)&c->h_idx_ring[k], (size_t)NB * sizeof(int32_t)));
@@ -348,6 +358,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->h_f_floats = (size_t)4 * (E > 64 ? E : 64);
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
+    c->n_groups = 1; c->groups_live = false; c->main_stream = c->stream;
+    for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) { c->gs[g] = nullptr; c->ev_fork[g] = c->ev_join[g] = nullptr; c->g_forked[g] = c->g_busy[g] = c->g_last[g] = c->g_dirty[g] = false; c->g_ticket[g] = 0; }
     c->multirank = 0; c->pending_n = -1; c->sal_dc = nullptr; c->sal_dx = nullptr; c->sal_src = nullptr;
     c->fc_wp = c->fc_wt = nullptr; c->fc_packed_valid = false;
     if (c->bf) { HIPC(dalloc(&c->fc_wp, (size_t)256 * 2048)); HIPC(dalloc(&c->fc_wt, (size_t)256 * 2048)); }
@@ -377,8 +389,10 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
 
 int mi_destroy(mi_ctx* c) {
     if (!c) return 0;
+    for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) if (c->gs[g]) hipStreamSynchronize(c->gs[g]);
     prof_harvest(c);
     hipStreamSynchronize(c->stream);
+    for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) if (c->gs[g]) { hipStreamDestroy(c->gs[g]); hipEventDestroy(c->ev_fork[g]); hipEventDestroy(c->ev_join[g]); }
     for (hipEvent_t e : c->prof.pool) hipEventDestroy(e);
     float* fl[] = {c->params, c->grads, c->adam_m, c->adam_v, c->rew, c->done, c->logp, c->adv, c->ret, c->value, c->obsf,
                    c->feat, c->dfeat, c->hout, c->dY, c->GC, c->GP[0], c->GP[1], c->GP[2], c->slabs, c->gemm_ws, c->col_ws,
@@ -410,7 +424,7 @@ void* mi_host_alloc(size_t bytes) {
 }
 void mi_host_free(void* p) { if (p) hipHostFree(p); }
 
-int mi_sync(mi_ctx* c) { ARG(c, "ctx"); HIPC(hipStreamSynchronize(c->stream)); return 0; }
+int mi_sync(mi_ctx* c) { ARG(c, "ctx"); JOIN(c); HIPC(hipStreamSynchronize(c->stream)); return 0; }
 
 int64_t mi_param_count(mi_ctx* c) { return c ? c->n_params : -1; }
 int mi_set_params(mi_ctx* c, const float* flat, int64_t n) { ARG(c && flat, "null"); c->fc_packed_valid = false; return upload_flat(c, c->params, flat, n); }
@@ -429,7 +443,7 @@ int mi_get_adam_state(mi_ctx* c, float* m, float* v, int64_t n) {
 
 // ------------------------------------------------------------------------------------------ rollout storage
 int mi_put_obs(mi_ctx* c, int32_t t, const void* obs, size_t bytes) {
-    ARG(c && obs, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    ARG(c && obs, "null"); JOIN(c); ARG(t >= 0 && t <= c->T, "t out of range");
     const size_t want = (size_t)c->E * c->obs_bytes_per_env;
     ARG(bytes == want, "obs byte count != E * bytes_per_env");
     char* dst = c->frames ? (char*)c->frames : (char*)c->obsf;
@@ -437,7 +451,7 @@ int mi_put_obs(mi_ctx* c, int32_t t, const void* obs, size_t bytes) {
     return 0;
 }
 int mi_get_obs(mi_ctx* c, int32_t t, void* obs, size_t bytes) {
-    ARG(c && obs, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    ARG(c && obs, "null"); JOIN(c); ARG(t >= 0 && t <= c->T, "t out of range");
     const size_t want = (size_t)c->E * c->obs_bytes_per_env;
     ARG(bytes == want, "obs byte count != E * bytes_per_env");
     const char* src = c->frames ? (const char*)c->frames : (const char*)c->obsf;
@@ -446,14 +460,14 @@ int mi_get_obs(mi_ctx* c, int32_t t, void* obs, size_t bytes) {
     return 0;
 }
 int mi_put_step(mi_ctx* c, int32_t t, const float* rew, const float* done) {
-    ARG(c && rew && done, "null"); ARG(t >= 0 && t < c->T, "t out of range");
+    ARG(c && rew && done, "null"); JOIN(c); ARG(t >= 0 && t < c->T, "t out of range");
     const size_t b = (size_t)c->E * sizeof(float);
     HIPC(hipMemcpyAsync(c->rew + (size_t)t * c->E, rew, b, hipMemcpyHostToDevice, c->stream));
     HIPC(hipMemcpyAsync(c->done + (size_t)t * c->E, done, b, hipMemcpyHostToDevice, c->stream));
     return 0;
 }
 int mi_put_policy_outputs(mi_ctx* c, int32_t t, const int32_t* act, const float* logp, const float* value) {
-    ARG(c, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    ARG(c, "null"); JOIN(c); ARG(t >= 0 && t <= c->T, "t out of range");
     const size_t E = c->E;
     if (act) { ARG(t < c->T, "act at t==T"); HIPC(hipMemcpyAsync(c->act + t * E, act, E * 4, hipMemcpyHostToDevice, c->stream)); }
     if (logp) { ARG(t < c->T, "logp at t==T"); HIPC(hipMemcpyAsync(c->logp + t * E, logp, E * 4, hipMemcpyHostToDevice, c->stream)); }
@@ -472,7 +486,7 @@ static float* field_ptr(mi_ctx* c, int f, int64_t* n) {
     }
 }
 int mi_read_field(mi_ctx* c, int32_t f, float* out, int64_t n) {
-    ARG(c && out, "null");
+    ARG(c && out, "null"); JOIN(c);
     if (f == MI_F_ACT) {
         ARG(n == (int64_t)c->T * c->E, "length");
         std::vector<int32_t> tmp(n);
@@ -488,7 +502,7 @@ int mi_read_field(mi_ctx* c, int32_t f, float* out, int64_t n) {
     return 0;
 }
 int mi_write_field(mi_ctx* c, int32_t f, const float* in, int64_t n) {
-    ARG(c && in, "null");
+    ARG(c && in, "null"); JOIN(c);
     if (f == MI_F_ACT) {
         ARG(n == (int64_t)c->T * c->E, "length");
         std::vector<int32_t> tmp(n);
@@ -514,6 +528,7 @@ static hipEvent_t prof_event(mi_ctx* c) {
 static void prof_harvest(mi_ctx* c) {
     if (c->prof.pend.empty()) return;
     hipStreamSynchronize(c->stream);
+    for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) if (c->gs[g]) hipStreamSynchronize(c->gs[g]);
     for (auto& p : c->prof.pend) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, p.a, p.b);
@@ -548,7 +563,7 @@ int mi_profile_enable(mi_ctx* c, int32_t enabled) {
 }
 const char* mi_profile_class_name(int32_t id) { return (id >= 0 && id < PC_COUNT) ? kProfNames[id] : ""; }
 int mi_profile_read(mi_ctx* c, double* rows, int32_t max_rows, int32_t* n_rows, int32_t reset) {
-    ARG(c && rows && n_rows, "null");
+    ARG(c && rows && n_rows, "null"); JOIN(c);
     prof_harvest(c);
     int n = 0;
     for (int ph = 0; ph < 2; ++ph)
@@ -655,16 +670,17 @@ static void linear_wgrad(mi_ctx* c, const float* dY, const float* X, int relu_x,
     launch_colsum_acc(dY, n, out, out, gb, c->col_ws, c->stream);
 }
 
-static void net_heads(mi_ctx* c, int n) {
-    linear_fwd(c, c->feat, 0, c->params + c->wh_off, c->params + c->bh_off, c->hout, n, c->H, c->A + 1, 0);
+static void net_heads(mi_ctx* c, int n, int soff = 0) {
+    linear_fwd(c, c->feat + (size_t)soff * c->H, 0, c->params + c->wh_off, c->params + c->bh_off, c->hout + (size_t)soff * (c->A + 1), n, c->H, c->A + 1, 0);
 }
 // h' = GRU(feat, h_state * (1 - done)); feat <- h' ; h_state <- h'   (n == E rows)
-static void net_gru(mi_ctx* c, int n) {
+static void net_gru(mi_ctx* c, int n, int soff = 0) {
     const int H = c->H;
-    launch_mask_rows(c->h_state, c->d_done, c->h_masked, n, H, c->stream);
-    linear_fwd(c, c->feat, 0, c->gru_wih, c->gru_bih, c->gru_gi, n, H, 3 * H, 0);
-    linear_fwd(c, c->h_masked, 0, c->gru_whh, c->gru_bhh, c->gru_gh, n, H, 3 * H, 0);
-    launch_gru_gates(c->gru_gi, c->gru_gh, c->h_masked, c->h_state, c->feat, n, H, c->stream);
+    const size_t o = (size_t)soff * H;
+    launch_mask_rows(c->h_state + o, c->d_done + soff, c->h_masked + o, n, H, c->stream);
+    linear_fwd(c, c->feat + o, 0, c->gru_wih, c->gru_bih, c->gru_gi + 3 * o, n, H, 3 * H, 0);
+    linear_fwd(c, c->h_masked + o, 0, c->gru_whh, c->gru_bhh, c->gru_gh + 3 * o, n, H, 3 * H, 0);
+    launch_gru_gates(c->gru_gi + 3 * o, c->gru_gh + 3 * o, c->h_masked + o, c->h_state + o, c->feat + o, n, H, c->stream);
 }
 
 static void fc_refresh(mi_ctx* c) {
@@ -676,12 +692,21 @@ static void fc_refresh(mi_ctx* c) {
     }
 }
 
-static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = false, bool with_heads = true, bool train = false) {
+// soff: first row of the activation buffers this pass may use (env groups of the pipelined rollout run side by side on
+// their own streams, each in its own rows); 0 everywhere else
+static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = false, bool with_heads = true, bool train = false, int soff = 0) {
     fc_refresh(c);          // bf16 mode: packed fc / conv filter images follow the parameters
+    float* const feat = c->feat + (size_t)soff * c->H;
     if (c->cfg.arch == MI_ARCH_IMPALA) {
         const float* prev = nullptr;
         for (int b = 0; b < 3; ++b) {
-            Block& k = c->blk[b];
+            Block k = c->blk[b];
+            if (soff) {         // shifted view of the block's buffers (element size: c->es bytes; arg-max: 1 byte)
+                const size_t pe = (size_t)(k.hin / 2) * (k.hin / 2) * k.cout, po = (size_t)soff * pe * (size_t)c->es;
+                auto sh = [&](float* q, size_t bytes) { return q ? (float*)((char*)q + bytes) : q; };
+                k.C = sh(k.C, po * 4); k.P0 = sh(k.P0, po); k.A1 = sh(k.A1, po); k.P1 = sh(k.P1, po); k.A2 = sh(k.A2, po); k.P2 = sh(k.P2, po);
+                k.PI += (size_t)soff * pe;
+            }
             const ConvLayer* L = &c->convs[b * 5];
             if (b == 0 && c->bf) {           // block1.conv + max pool fused: the 64x64x16 conv output never reaches HBM
                 ConvArgs a{};
@@ -716,22 +741,26 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
             }
             prev = k.P2;
         }
+        const float* last_p2 = prev;
         if (c->bf) {                            // bf16 matrix cores on the packed [256][2048] weight image (fc_bf16.hip)
             ProfScope ps(c, PC_GEMM, n, 2.0 * n * 2048 + 2.0 * 2048 * 256 + 4.0 * n * 256, 2.0 * n * 2048 * 256);
-            if (n >= 1024) launch_fc_fwd_bf16(c->blk[2].P2, c->fc_wp, c->params + c->fc.b_off, c->feat, n, c->stream);
-            else launch_fc_fwd_small_bf16(c->blk[2].P2, c->fc_wp, c->params + c->fc.b_off, c->feat, n, c->stream);   // rollout-sized: latency-bound
+            if (n >= 1024) launch_fc_fwd_bf16(last_p2, c->fc_wp, c->params + c->fc.b_off, feat, n, c->stream);
+            else launch_fc_fwd_small_bf16(last_p2, c->fc_wp, c->params + c->fc.b_off, feat, n, c->stream);   // rollout-sized: latency-bound
         } else
-            linear_fwd(c, c->blk[2].P2, 1, c->params + c->fc.w_off, c->params + c->fc.b_off, c->feat, n, 2048, c->H, 1, c->bf);
+            linear_fwd(c, last_p2, 1, c->params + c->fc.w_off, c->params + c->fc.b_off, feat, n, 2048, c->H, 1, c->bf);
     } else {
-        launch_gather_rows((const float*)src.base, src.idx, src.first, c->mlp_act[0], n, c->cfg.obs_dim, c->stream);
+        float* x0 = c->mlp_act[0] + (size_t)soff * c->cfg.obs_dim;
+        launch_gather_rows((const float*)src.base, src.idx, src.first, x0, n, c->cfg.obs_dim, c->stream);
         const size_t L = c->mlp.size();
+        const float* x = x0;
         for (size_t l = 0; l < L; ++l) {
-            float* y = (l + 1 == L) ? c->feat : c->mlp_act[l + 1];
-            linear_fwd(c, c->mlp_act[l], 0, c->params + c->mlp[l].w_off, c->params + c->mlp[l].b_off, y, n, c->mlp[l].in, c->mlp[l].out, l + 1 < L);
+            float* y = (l + 1 == L) ? feat : c->mlp_act[l + 1] + (size_t)soff * c->mlp[l].out;
+            linear_fwd(c, x, 0, c->params + c->mlp[l].w_off, c->params + c->mlp[l].b_off, y, n, c->mlp[l].in, c->mlp[l].out, l + 1 < L);
+            x = y;
         }
     }
-    if (recurrent && c->gru_on) net_gru(c, n);
-    if (with_heads) net_heads(c, n);
+    if (recurrent && c->gru_on) net_gru(c, n, soff);
+    if (with_heads) net_heads(c, n, soff);
 }
 
 // backward from dY (n x (A+1)); gradients accumulate into c->grads
@@ -866,7 +895,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
 
 // ------------------------------------------------------------------------------------------ predict / forward
 int mi_policy_step(mi_ctx* c, int32_t t, uint64_t seed, const float* u, int64_t* act_out, float* logp_out, float* value_out) {
-    ARG(c, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    ARG(c, "null"); JOIN(c); ARG(t >= 0 && t <= c->T, "t out of range");
     const int E = c->E;
     InputSrc src{c->frames ? (const void*)c->frames : (const void*)c->obsf, nullptr, (long long)t * E};
     const float* du = nullptr;
@@ -890,7 +919,7 @@ int mi_policy_step(mi_ctx* c, int32_t t, uint64_t seed, const float* u, int64_t*
 
 int mi_rollout_step(mi_ctx* c, int32_t t, const float* rew_prev, const float* done_prev, uint64_t seed, const float* u,
                     int64_t* act_out, float* logp_out, float* value_out) {
-    ARG(c, "null"); ARG(t >= 0 && t <= c->T, "t out of range");
+    ARG(c, "null"); JOIN(c); ARG(t >= 0 && t <= c->T, "t out of range");
     const int E = c->E;
     if (rew_prev || done_prev) {
         ARG(rew_prev && done_prev && t >= 1, "rew_prev/done_prev come together and belong to step t-1");
@@ -933,9 +962,114 @@ int mi_rollout_step(mi_ctx* c, int32_t t, const float* rew_prev, const float* do
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------ pipelined rollout (env groups)
+// The reference's loop (agents/ppo.py:225-236) is strictly serial per step: obs -> H2D -> forward -> D2H act -> env.step.  An env's
+// next frame depends only on its OWN action, so the E envs split into G contiguous groups whose chains
+//     upload frames(t, g) -> forward + sample (t, g) -> actions on the host -> [env.step of group g on the host] -> upload frames(t+1, g)
+// are independent: group g's upload (PCIe, ~37 us for 128 frames) and forward run on stream gs[g] while the host waits for / steps
+// another group.  Per group: its own stream, rows [e0, e0 + E/G) of the activation buffers, its slice of the pinned hand-off
+// buffers, its own completion ticket.  Numbers are those of mi_rollout_step (same kernels, same Philox counters t*E + e).
+static int join_groups(mi_ctx* c) {
+    for (int g = 0; g < c->n_groups; ++g) {
+        if (!c->gs[g]) continue;
+        if (c->g_dirty[g]) {
+            HIPC(hipEventRecord(c->ev_join[g], c->gs[g]));
+            HIPC(hipStreamWaitEvent(c->main_stream, c->ev_join[g], 0));
+            c->g_dirty[g] = false;
+        }
+        c->g_forked[g] = false;          // the next submit of this group orders itself behind the main stream again
+    }
+    c->groups_live = false;
+    return 0;
+}
+
+int mi_rollout_groups(mi_ctx* c, int32_t n_groups) {
+    ARG(c, "null"); ARG(n_groups >= 1 && n_groups <= mi_ctx::MAX_GROUPS, "1 .. 4 groups");
+    ARG(c->E % n_groups == 0, "n_envs must be divisible by the number of groups");
+    for (int g = 0; g < c->n_groups; ++g) ARG(!c->g_busy[g], "a group step is still in flight: mi_rollout_wait it first");
+    JOIN(c);
+    for (int g = 0; g < n_groups; ++g)
+        if (!c->gs[g]) {
+            HIPC(hipStreamCreateWithFlags(&c->gs[g], hipStreamNonBlocking));
+            HIPC(hipEventCreateWithFlags(&c->ev_fork[g], hipEventDisableTiming));
+            HIPC(hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming));
+        }
+    c->n_groups = n_groups;
+    return 0;
+}
+
+int mi_rollout_submit(mi_ctx* c, int32_t t, int32_t g, const void* frames, size_t bytes, const float* rew_prev, const float* done_prev,
+                      uint64_t seed, const float* u) {
+    ARG(c, "null"); ARG(t >= 0 && t <= c->T, "t out of range"); ARG(g >= 0 && g < c->n_groups, "group out of range");
+    ARG(c->gs[g], "call mi_rollout_groups first"); ARG(!c->g_busy[g], "this group's previous step has not been waited for");
+    ARG(c->pending_n < 0, "a multirank minibatch is pending");
+    const int E = c->E, ng = E / c->n_groups, e0 = g * ng;
+    ARG(!frames || bytes == (size_t)ng * c->obs_bytes_per_env, "frames byte count != (E / groups) * bytes_per_env");
+    if (rew_prev || done_prev) ARG(rew_prev && done_prev && t >= 1, "rew_prev/done_prev come together and belong to step t-1");
+    hipStream_t st = c->gs[g];
+    if (!c->g_forked[g]) {               // first step since the main stream last worked: parameters / packed banks must be in place
+        fc_refresh(c);
+        HIPC(hipEventRecord(c->ev_fork[g], c->main_stream));
+        HIPC(hipStreamWaitEvent(st, c->ev_fork[g], 0));
+        c->g_forked[g] = true;
+    }
+    c->groups_live = true; c->g_dirty[g] = true;
+    char* ring = c->frames ? (char*)c->frames : (char*)c->obsf;
+    if (frames) HIPC(hipMemcpyAsync(ring + ((size_t)t * E + e0) * c->obs_bytes_per_env, frames, bytes, hipMemcpyHostToDevice, st));
+    float* h_rd = c->h_rd + 2 * e0;      // this group's {rew[ng], done[ng]} (pinned, device-visible)
+    const bool have_rd = rew_prev != nullptr;
+    if (have_rd) {
+        memcpy(h_rd, rew_prev, (size_t)ng * 4); memcpy(h_rd + ng, done_prev, (size_t)ng * 4);
+        if (c->gru_on) HIPC(hipMemcpyAsync(c->d_done + e0, h_rd + ng, (size_t)ng * 4, hipMemcpyHostToDevice, st));
+    }
+    const float* du = nullptr;
+    if (u) { HIPC(hipMemcpyAsync(c->d_u + e0, u, (size_t)ng * 4, hipMemcpyHostToDevice, st)); du = c->d_u + e0; }
+    const bool last = (t == c->T);
+    {
+        // issue this group's pass on its stream, with its slice of the split-K workspace (two groups' GEMMs run concurrently)
+        struct Scope { mi_ctx* c; hipStream_t s; float* w; size_t wf; ~Scope() { c->stream = s; c->gemm_ws = w; c->gemm_ws_floats = wf; } } sc{c, c->stream, c->gemm_ws, c->gemm_ws_floats};
+        const size_t slice = c->gemm_ws_floats / mi_ctx::MAX_GROUPS;
+        c->stream = st; c->gemm_ws = sc.w + (size_t)g * slice; c->gemm_ws_floats = slice;
+        c->prof.phase = 0;
+        InputSrc src{c->frames ? (const void*)c->frames : (const void*)c->obsf, nullptr, (long long)t * E + e0};
+        net_forward(c, src, ng, true, false, false, e0);
+        const size_t o = (size_t)t * E + e0;
+        launch_heads_sample(c->feat + (size_t)e0 * c->H, c->params + c->wh_off, c->params + c->bh_off, ng, c->H, c->A, du, seed, (unsigned long long)t * E + e0,
+                            last ? nullptr : c->act + o, last ? nullptr : c->logp + o, c->value + o, c->h_pack + 3 * e0, nullptr,
+                            have_rd ? h_rd : nullptr, have_rd ? c->rew + o - E : nullptr, have_rd ? c->done + o - E : nullptr, st,
+                            c->d_done_ctr + 1 + g, c->h_flag + 1 + g, ++c->g_ticket[g]);
+    }
+    HIPC(hipGetLastError()); NETCHK(c);
+    c->g_busy[g] = true; c->g_last[g] = last;
+    return 0;
+}
+
+int mi_rollout_wait(mi_ctx* c, int32_t g, int64_t* act_out, float* logp_out, float* value_out) {
+    ARG(c, "null"); ARG(g >= 0 && g < c->n_groups, "group out of range"); ARG(c->g_busy[g], "nothing submitted for this group");
+    const int ng = c->E / c->n_groups, e0 = g * ng;
+    const unsigned want = c->g_ticket[g];
+    volatile unsigned* flag = c->h_flag + 1 + g;
+    bool seen = false;
+    for (unsigned long long spin = 0; spin < (1ull << 34); ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+        __builtin_ia32_pause();
+        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(c->gs[g]) != hipErrorNotReady) break;     // finished without a ticket, or failed
+    }
+    c->g_busy[g] = false;
+    if (!seen) HIPC(hipStreamSynchronize(c->gs[g]));
+    const float* pk = c->h_pack + 3 * e0;
+    const bool last = c->g_last[g];
+    for (int e = 0; e < ng; ++e) {
+        if (act_out && !last) act_out[e] = (int64_t)pk[3 * e];
+        if (logp_out && !last) logp_out[e] = pk[3 * e + 1];
+        if (value_out) value_out[e] = pk[3 * e + 2];
+    }
+    return 0;
+}
+
 int mi_predict_staged(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
                       int64_t* act_out, float* logp_out, float* value_out) {
-    ARG(c && obs, "null");
+    ARG(c && obs, "null"); JOIN(c);
     const int E = c->E;
     ARG(bytes == (size_t)E * c->obs_bytes_per_env, "obs byte count != E * bytes_per_env");
     void* stage = c->stage_frames ? (void*)c->stage_frames : (void*)c->stage_obs;
@@ -963,7 +1097,7 @@ int mi_predict_staged(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, u
 // so it must not be called between mi_minibatch and mi_optimizer_step of an accumulating update.
 int mi_value_saliency(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
                       int64_t* act_out, float* logp_out, float* value_out, float* grad_out) {
-    ARG(c && obs && grad_out, "null");
+    ARG(c && obs && grad_out, "null"); JOIN(c);
     ARG(!c->gru_on, "value saliency through the GRU is not built");
     ARG(c->pending_n < 0, "a multirank minibatch is pending");
     const int E = c->E;
@@ -1009,7 +1143,7 @@ int mi_value_saliency(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, u
 }
 
 int mi_commit_staged(mi_ctx* c, int32_t t) {
-    ARG(c, "null"); ARG(t >= 0 && t <= c->T, "t out of range"); ARG(c->staged_valid, "nothing staged: call mi_predict_staged first");
+    ARG(c, "null"); JOIN(c); ARG(t >= 0 && t <= c->T, "t out of range"); ARG(c->staged_valid, "nothing staged: call mi_predict_staged first");
     const size_t E = c->E, ob = E * c->obs_bytes_per_env;
     char* ring = c->frames ? (char*)c->frames : (char*)c->obsf;
     const void* stage = c->stage_frames ? (const void*)c->stage_frames : (const void*)c->stage_obs;
@@ -1023,7 +1157,7 @@ int mi_commit_staged(mi_ctx* c, int32_t t) {
 }
 
 int mi_set_gru(mi_ctx* c, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh) {
-    ARG(c && w_ih && w_hh && b_ih && b_hh, "null");
+    ARG(c && w_ih && w_hh && b_ih && b_hh, "null"); JOIN(c);
     const size_t H = c->H, E = c->E;
     if (!c->gru_wih) {
         HIPC(dalloc(&c->gru_wih, 3 * H * H)); HIPC(dalloc(&c->gru_whh, 3 * H * H)); HIPC(dalloc(&c->gru_bih, 3 * H)); HIPC(dalloc(&c->gru_bhh, 3 * H));
@@ -1036,7 +1170,7 @@ int mi_set_gru(mi_ctx* c, const float* w_ih, const float* w_hh, const float* b_i
     return 0;
 }
 int mi_rec_state(mi_ctx* c, const float* hidden, const float* done) {
-    ARG(c, "null"); ARG(c->gru_on, "no GRU set: call mi_set_gru first");
+    ARG(c, "null"); JOIN(c); ARG(c->gru_on, "no GRU set: call mi_set_gru first");
     const size_t H = c->H, E = c->E;
     if (hidden) HIPC(hipMemcpyAsync(c->h_state, hidden, E * H * 4, hipMemcpyHostToDevice, c->stream));
     if (done) HIPC(hipMemcpyAsync(c->d_done, done, E * 4, hipMemcpyHostToDevice, c->stream));
@@ -1045,7 +1179,7 @@ int mi_rec_state(mi_ctx* c, const float* hidden, const float* done) {
     return 0;
 }
 int mi_get_hidden(mi_ctx* c, float* hidden) {
-    ARG(c && hidden, "null"); ARG(c->gru_on, "no GRU set");
+    ARG(c && hidden, "null"); JOIN(c); ARG(c->gru_on, "no GRU set");
     HIPC(hipMemcpyAsync(hidden, c->h_state, (size_t)c->E * c->H * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     return 0;
@@ -1061,7 +1195,7 @@ int mi_forward(mi_ctx* c, const void* obs, int32_t n, float* logp_all, float* va
     return forward_common(c, obs, n, false, logp_all, value, feat);
 }
 static int forward_common(mi_ctx* c, const void* obs, int32_t n, bool recurrent, float* logp_all, float* value, float* feat) {
-    ARG(c && obs, "null"); ARG(n >= 1 && n <= c->NB, "n must be in [1, max_batch]");
+    ARG(c && obs, "null"); JOIN(c); ARG(n >= 1 && n <= c->NB, "n must be in [1, max_batch]");
     c->staged_valid = false;
     void* stage = c->stage_frames ? (void*)c->stage_frames : (void*)c->stage_obs;
     HIPC(hipMemcpyAsync(stage, obs, (size_t)n * c->obs_bytes_per_env, hipMemcpyHostToDevice, c->stream));
@@ -1080,7 +1214,7 @@ static int forward_common(mi_ctx* c, const void* obs, int32_t n, bool recurrent,
 
 // ------------------------------------------------------------------------------------------ estimates
 int mi_compute_estimates(mi_ctx* c, float gamma, float lmbda, int32_t use_gae, int32_t normalize_adv) {
-    ARG(c, "null");
+    ARG(c, "null"); JOIN(c);
     launch_gae(c->rew, c->done, c->value, c->adv, c->ret, c->T, c->E, gamma, lmbda, use_gae, c->stream);
     if (normalize_adv) {
         launch_advnorm_stats(c->adv, c->T * c->E, c->adv_stats, c->stream);
@@ -1090,14 +1224,14 @@ int mi_compute_estimates(mi_ctx* c, float gamma, float lmbda, int32_t use_gae, i
     return 0;
 }
 int mi_adv_stats(mi_ctx* c, double s[3]) {
-    ARG(c && s, "null");
+    ARG(c && s, "null"); JOIN(c);
     launch_advnorm_stats(c->adv, c->T * c->E, c->adv_stats, c->stream);
     HIPC(hipMemcpyAsync(s, c->adv_stats, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     return 0;
 }
 int mi_adv_apply(mi_ctx* c, const double s[3]) {
-    ARG(c && s, "null");
+    ARG(c && s, "null"); JOIN(c);
     HIPC(hipMemcpyAsync(c->adv_stats, s, 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     launch_advnorm_apply(c->adv, c->T * c->E, c->adv_stats, c->stream);
@@ -1116,7 +1250,7 @@ static InputSrc minibatch_src(mi_ctx* c) {
 // sums the gradients of the accumulated minibatches before the optimizer step, so only the fp32 summation order changes); it
 // needs a loss without batch-level terms (x_entropy_coef == 0, fs_coef == 0).
 static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_t* seg_n, int32_t n_seg, int32_t n_global, const mi_hparams* hp) {
-    ARG(c && hp, "null"); ARG(n >= 0 && n <= c->NB, "n_idx must be in [0, max_batch]"); ARG(n_global >= 1, "n_global");
+    ARG(c && hp, "null"); JOIN(c); ARG(n >= 0 && n <= c->NB, "n_idx must be in [0, max_batch]"); ARG(n_global >= 1, "n_global");
     ARG(n == 0 || idx, "idx"); ARG(n_seg >= 1 && n_seg <= MI_MAX_SEG && seg_n, "1 .. 16 segments");
     ARG(c->log_count + n_seg <= c->log_cap, "loss log full: call mi_loss_log_read(reset=1)");
     ARG(c->pending_n < 0, "previous multirank minibatch not finished");
@@ -1190,7 +1324,7 @@ int mi_set_multirank(mi_ctx* c, int32_t enabled) { ARG(c, "null"); ARG(enabled >
 
 // multirank mode 2: after the caller summed stats_ring[0 .. log_count*32) over the ranks, derive every minibatch's log record
 int mi_loss_log_finalize(mi_ctx* c) {
-    ARG(c, "null"); ARG(c->multirank == 2, "only in multirank mode 2");
+    ARG(c, "null"); JOIN(c); ARG(c->multirank == 2, "only in multirank mode 2");
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
     launch_loss_finalize_records(c->ring_args, c->log_count, c->stats_ring, impala ? c->fs_ring : nullptr, c->loss_log, c->stream);
     HIPC(hipGetLastError()); NETCHK(c);
@@ -1198,7 +1332,7 @@ int mi_loss_log_finalize(mi_ctx* c) {
 }
 
 int mi_minibatch_finish(mi_ctx* c) {
-    ARG(c, "null"); ARG(c->pending_n >= 0, "no pending minibatch");
+    ARG(c, "null"); JOIN(c); ARG(c->pending_n >= 0, "no pending minibatch");
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
     float* slot = c->loss_log + (size_t)c->log_count * 8;
     launch_loss_finalize(c->pending, 0, 2, impala ? c->fs_val : nullptr, slot, c->stream);
@@ -1212,7 +1346,7 @@ int mi_minibatch_finish(mi_ctx* c) {
 }
 
 int mi_optimizer_step(mi_ctx* c, float lr, float max_norm, int32_t step, float* gnorm_out) {
-    ARG(c, "null"); ARG(step >= 1, "adam_step is 1-based");
+    ARG(c, "null"); JOIN(c); ARG(step >= 1, "adam_step is 1-based");
     const double b1 = 0.9, b2 = 0.999;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
@@ -1230,7 +1364,7 @@ int mi_optimizer_step(mi_ctx* c, float lr, float max_norm, int32_t step, float* 
 }
 
 int mi_loss_log_read(mi_ctx* c, float* out, int32_t max_records, int32_t* n_records, int32_t reset) {
-    ARG(c && n_records, "null");
+    ARG(c && n_records, "null"); JOIN(c);
     const int n = c->log_count < max_records ? c->log_count : max_records;
     if (out && n > 0) {
         HIPC(hipMemcpyAsync(out, c->loss_log, (size_t)n * 8 * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1242,7 +1376,7 @@ int mi_loss_log_read(mi_ctx* c, float* out, int32_t max_records, int32_t* n_reco
 }
 
 int mi_device_ptr(mi_ctx* c, int32_t which, void** ptr, int64_t* n) {
-    ARG(c && ptr && n, "null");
+    ARG(c && ptr && n, "null"); JOIN(c);
     switch (which) {
         case MI_PTR_GRADS: *ptr = c->grads; *n = c->n_params; return 0;
         case MI_PTR_LOSS_STATS: *ptr = c->loss_stats; *n = 32; return 0;
@@ -1286,7 +1420,7 @@ static int download_act(mi_ctx* c, const void* dev, float* host, size_t n) {
 int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw, int32_t n, const void* in, int32_t in_is_u8,
                   int32_t relu_in, const float* w_ref, const float* bias, const float* res, const float* mask, const float* dout,
                   float* out, float* dbias_out) {
-    ARG(c && w_ref && out && n >= 1, "null");
+    ARG(c && w_ref && out && n >= 1, "null"); JOIN(c);
     ConvShape s;
     if (shape_of(cin, cout, hw, &s)) return -1;
     ARG((s == CS_3_16_64) == (in_is_u8 != 0) || mode == 1, "block1.conv takes uint8 frames");
@@ -1406,7 +1540,7 @@ int mi_op_conv3x3(mi_ctx* c, int32_t mode, int32_t cin, int32_t cout, int32_t hw
 // mode 1: (dy = x, a_fwd, x_fwd, w1, w2) -> out_a = d a = convT2(dy) * (a_fwd > 0), out_y = d x = convT1(d a) * (x_fwd > 0) + dy.
 int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, const float* x, const float* w1_ref, const float* b1,
                    const float* w2_ref, const float* b2, const float* a_fwd, const float* x_fwd, float* out_a, float* out_y) {
-    ARG(c && x && w1_ref && w2_ref && out_a && out_y && n >= 1, "null");
+    ARG(c && x && w1_ref && w2_ref && out_a && out_y && n >= 1, "null"); JOIN(c);
     ARG(c->bf, "the fused residual-block kernels exist in bf16 precision only");
     ARG((mode == 0 || mode == 3) ? (b1 && b2) : (a_fwd && x_fwd), "modes 0 / 3 need the biases, modes 1 / 2 the forward tensors");
     ConvShape s;
@@ -1473,7 +1607,7 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
 }
 
 int mi_op_maxpool(mi_ctx* c, int32_t mode, int32_t n, int32_t hw, int32_t ch, const float* in, const float* dout, float* out) {
-    ARG(c && in && out, "null"); ARG(n >= 1, "n");
+    ARG(c && in && out, "null"); JOIN(c); ARG(n >= 1, "n");
     ARG((hw == 64 && ch == 16) || (hw == 32 && ch == 32) || (hw == 16 && ch == 32), "max pool shapes of the IMPALA blocks only: (64,16), (32,32), (16,32)");
     const size_t X = (size_t)n * hw * hw * ch, p = X / 4;
     void *din = nullptr, *dp = nullptr, *dd = nullptr, *dg = nullptr; uint8_t* di = nullptr;
@@ -1496,7 +1630,7 @@ int mi_op_maxpool(mi_ctx* c, int32_t mode, int32_t n, int32_t hw, int32_t ch, co
 
 int mi_op_gemm(mi_ctx* c, int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
                int64_t sbn, float* C) {
-    ARG(c && A && B && C, "null");
+    ARG(c && A && B && C, "null"); JOIN(c);
     const size_t na = (size_t)((M - 1) * sam + (K - 1) * sak + 1), nb = (size_t)((K - 1) * sbk + (N - 1) * sbn + 1);
     float *da = nullptr, *db = nullptr, *dc = nullptr;
     HIPC(dalloc(&da, na)); HIPC(dalloc(&db, nb)); HIPC(dalloc(&dc, (size_t)M * N));
@@ -1522,7 +1656,7 @@ __global__ void mfma_selftest_kernel(float* d) {
     for (int r = 0; r < 4; ++r) d[(q * 4 + r) * 16 + i] = acc[r];
 }
 int mi_selftest_mfma(mi_ctx* c, float* max_err) {
-    ARG(c && max_err, "null");
+    ARG(c && max_err, "null"); JOIN(c);
     float* d = nullptr;
     HIPC(dalloc(&d, 256));
     hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, c->stream, d);

@@ -39,7 +39,7 @@ def lib_path():
 
 EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_param_count mi_set_params "
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
-           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
+           "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_rollout_groups mi_rollout_submit mi_rollout_wait mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_minibatch_multi mi_optimizer_step mi_loss_log_read mi_device_ptr "
            "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
 
@@ -64,6 +64,8 @@ def load_library():
     # the per-env-step entry point is called T+1 times per iteration: declared argtypes let plain ints / addresses through
     # without building ctypes wrapper objects on every call
     lib.mi_rollout_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mi_rollout_submit.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.mi_rollout_wait.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -216,6 +218,35 @@ class Engine:
         if rc:
             self._chk(rc)
         return out[:2 * E].view(np.int64), out[2 * E:3 * E], out[3 * E:]
+
+    # pipelined rollout: env groups, submit / wait (see include/mi355ppo.h)
+    def rollout_groups(self, n_groups):
+        self._chk(self.lib.mi_rollout_groups(self._ctx, C.c_int32(n_groups)))
+        self.n_groups = n_groups
+
+    def rollout_submit(self, t, group, frames=None, rew_prev=None, done_prev=None, seed=0, u=None):
+        """frames: this group's observations in PINNED memory (Engine.pinned), kept unchanged until rollout_wait(group); None = slot t holds them."""
+        addr = lambda a: None if a is None else a.__array_interface__['data'][0]
+        if rew_prev is not None and (rew_prev.dtype != np.float32 or not rew_prev.flags.c_contiguous):
+            rew_prev = _f32(rew_prev)
+        if done_prev is not None and (done_prev.dtype != np.float32 or not done_prev.flags.c_contiguous):
+            done_prev = _f32(done_prev)
+        u = None if u is None else _f32(u)
+        if frames is not None and not frames.flags.c_contiguous:
+            raise EngineError("rollout_submit needs a contiguous (pinned) frame buffer")
+        rc = self.lib.mi_rollout_submit(self._ctx, t, group, addr(frames), 0 if frames is None else frames.nbytes, addr(rew_prev), addr(done_prev), seed, addr(u))
+        if rc:
+            self._chk(rc)
+        self._keep_alive = (frames, rew_prev, done_prev, u)
+
+    def rollout_wait(self, group):
+        n = self.E // getattr(self, "n_groups", 1)
+        out = np.empty(4 * n, np.float32)                       # [act as int64 | logp | value]
+        p = out.__array_interface__['data'][0]
+        rc = self.lib.mi_rollout_wait(self._ctx, group, p, p + 8 * n, p + 12 * n)
+        if rc:
+            self._chk(rc)
+        return out[:2 * n].view(np.int64), out[2 * n:3 * n], out[3 * n:]
 
     def predict_staged(self, obs, seed=0, counter=0, u=None):
         want = np.uint8 if self.arch == ARCH_IMPALA else np.float32
