@@ -198,6 +198,10 @@ int mi_op_maxpool(mi_ctx* ctx, int32_t mode /*0 fwd,1 bwd*/, int32_t n, int32_t 
 int mi_op_gemm(mi_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak,
                const float* B, int64_t sbk, int64_t sbn, float* C);
 int mi_selftest_mfma(mi_ctx* ctx, float* max_err);
+/* what the last mi_minibatch left in the activation buffers (first n samples), fp32 NHWC: which = 8 * block + k, k = 0 pooled map,
+ * 1 res1.conv1 out, 2 res1 out, 3 res2.conv1 out, 4 block out, 5 max-pool arg-max (window position ky*3+kx); which = 100: features.
+ * Lets a parity test run the oracle's backward pass on the ENGINE's forward tensors (teacher forcing, tests/test_gpu_bf16.py). */
+int mi_debug_read(mi_ctx* ctx, int32_t which, int32_t n, float* out);
 
 #ifdef __cplusplus
 }

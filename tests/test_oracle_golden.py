@@ -206,3 +206,39 @@ def test_g9_recurrent_predict():
             np.testing.assert_allclose(h.numpy(), z[f"hx{t}"], rtol=0, atol=2e-6)
             np.testing.assert_allclose(lp.numpy(), z[f"logits{t}"], rtol=0, atol=2e-6)
             np.testing.assert_allclose(v.numpy(), z[f"value{t}"], rtol=0, atol=2e-6)
+
+
+def test_bf16_oracle_without_rounding_is_the_fp32_oracle():
+    """oracle/ppo_oracle_bf16.py writes the IMPALA backward pass out by hand (so that it can round where the bf16 kernels round).
+    With the rounding switched off it must be the reference's own numbers: G4 losses (2e-6) and every stored gradient tensor of
+    the reference (1e-4 relative), and the fp32 oracle's autograd on all 36 tensors."""
+    from oracle import ppo_oracle_bf16 as OB
+    z = load_npz("g4_impala_lossgrad.npz")
+    params = npz_params(load_npz("g3_impala_forward.npz"))
+    T, E = 4, 8
+    fr = z["in/frames"][:T].reshape(T * E, 64, 64, 3)
+    f = lambda k: torch.from_numpy(np.ascontiguousarray(z[k]).reshape(-1)[:T * E].astype(np.float32))
+    act, logp, val = f("in/act"), f("in/logp"), torch.from_numpy(z["in/val"][:T].reshape(-1))
+    ret, adv = torch.from_numpy(z["ret"].reshape(-1)), torch.from_numpy(z["adv"].reshape(-1))
+    for tag, xc in (("raw", 0.0), ("xent", 0.05)):
+        L, g = OB.loss_and_grads(params, fr, act, logp, val, ret, adv, x_entropy_coef=xc, rounding=False)
+        ref = npz_json(z, f"{tag}/summary")
+        assert abs(-L["pi_loss"] - ref["Loss/pi"]) < 2e-6 and abs(-L["value_loss"] - ref["Loss/v"]) < 2e-6 * max(1, abs(ref["Loss/v"]))
+        assert abs(L["entropy"] - ref["Loss/entropy"]) < 2e-6 and abs(L["total"] - ref["Loss/total"]) < 2e-6 * max(1, abs(ref["Loss/total"]))
+        assert abs(L["fs"] - ref["Loss/feature_sparsity"]) < 2e-6
+        for k in z.files:
+            if k.startswith(f"{tag}/g/"):
+                r = z[k].astype(np.float64)
+                m = g[k[len(tag) + 3:]].numpy().astype(np.float64)
+                assert np.sqrt(((m - r) ** 2).sum()) < 1e-4 * np.sqrt((r ** 2).sum()) + 1e-9, k
+        for k, (nrm, _) in npz_json(z, f"{tag}/grad_stats").items():
+            assert abs(float((g[k].double() ** 2).sum().sqrt()) - nrm) < 1e-4 * nrm + 1e-9, k
+        ag = O.OraclePPO(params, "impala", T, E, x_entropy_coef=xc)
+        _, g32 = ag.loss_and_grads(O.frames_to_obs(fr), act, logp, val, ret, adv)
+        for k in g32:
+            d = (g[k].double() - g32[k].double()).norm() / (g32[k].double().norm() + 1e-12)
+            assert d < 1e-4, (k, float(d))
+    # and the rounding does something, but not much: bf16 storage moves the losses by < 1e-2
+    L0, _ = OB.loss_and_grads(params, fr, act, logp, val, ret, adv, rounding=False)
+    Lb, gb = OB.loss_and_grads(params, fr, act, logp, val, ret, adv, rounding=True)
+    assert 0 < abs(Lb["total"] - L0["total"]) + abs(Lb["value_loss"] - L0["value_loss"]) and abs(Lb["pi_loss"] - L0["pi_loss"]) < 1e-2

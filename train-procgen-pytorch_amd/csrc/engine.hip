@@ -1606,6 +1606,30 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
     return 0;
 }
 
+// Read back what the last training-mode pass (mi_minibatch) left in the activation buffers, as fp32 NHWC: which = 8 * block + k with
+// k = 0 P0 (pooled map), 1 A1, 2 P1, 3 A2, 4 P2 (res1.conv1 out, res1 out, res2.conv1 out, block out), 5 the max-pool arg-max bytes
+// (window position ky*3+kx as float); which = 100: the 256 features.  For teacher-forced backward parity tests.
+int mi_debug_read(mi_ctx* c, int32_t which, int32_t n, float* out) {
+    ARG(c && out, "null"); JOIN(c); ARG(n >= 1 && n <= c->NB, "n must be in [1, max_batch]");
+    if (which == 100) {
+        HIPC(hipMemcpyAsync(out, c->feat, (size_t)n * c->H * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    ARG(c->cfg.arch == MI_ARCH_IMPALA && which >= 0 && which < 24 && (which & 7) <= 5, "which");
+    const Block& k = c->blk[which >> 3];
+    const size_t pe = (size_t)n * (k.hin / 2) * (k.hin / 2) * k.cout;
+    HIPC(hipStreamSynchronize(c->stream));
+    if ((which & 7) == 5) {
+        std::vector<uint8_t> h(pe);
+        HIPC(hipMemcpy(h.data(), k.PI, pe, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < pe; ++i) out[i] = (float)h[i];
+        return 0;
+    }
+    const float* src[5] = {k.P0, k.A1, k.P1, k.A2, k.P2};
+    return download_act(c, src[which & 7], out, pe);
+}
+
 int mi_op_maxpool(mi_ctx* c, int32_t mode, int32_t n, int32_t hw, int32_t ch, const float* in, const float* dout, float* out) {
     ARG(c && in && out, "null"); JOIN(c); ARG(n >= 1, "n");
     ARG((hw == 64 && ch == 16) || (hw == 32 && ch == 32) || (hw == 16 && ch == 32), "max pool shapes of the IMPALA blocks only: (64,16), (32,32), (16,32)");

@@ -41,7 +41,7 @@ EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_fre
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
            "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_rollout_groups mi_rollout_submit mi_rollout_wait mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_minibatch_multi mi_optimizer_step mi_loss_log_read mi_device_ptr "
-           "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma").split()
+           "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma mi_debug_read").split()
 
 
 def load_library():
@@ -426,6 +426,17 @@ class Engine:
         out = np.empty((M, N), np.float32)
         self._chk(self.lib.mi_op_gemm(self._ctx, C.c_int32(M), C.c_int32(N), C.c_int32(K), _fp(A), C.c_int64(sam),
                                       C.c_int64(sak), _fp(B), C.c_int64(sbk), C.c_int64(sbn), _fp(out)))
+        return out
+
+    def debug_read(self, which, n):
+        """Activation tensor `which` (see include/mi355ppo.h mi_debug_read) of the last minibatch pass, first n samples, fp32 NHWC."""
+        if which == 100:
+            out = np.empty((n, self.H), np.float32)
+        else:
+            b = which >> 3
+            hw, ch = (32, 16, 8)[b], (16, 32, 32)[b]
+            out = np.empty((n, hw, hw, ch), np.float32)
+        self._chk(self.lib.mi_debug_read(self._ctx, C.c_int32(which), C.c_int32(n), _fp(out)))
         return out
 
     def selftest_mfma(self):
