@@ -64,7 +64,7 @@ def impala_forward(p, frames_u8, rounding=True, dtype=torch.float32):
     return feat, cache, fs
 
 
-def impala_backward(p, cache, dfeat_post, feat, rounding=True, dtype=torch.float32):
+def impala_backward(p, cache, dfeat_post, feat, rounding=True, dtype=torch.float32, fs_coef=0.0):
     """Backward of the bf16 engine from d loss / d feat (after the fc ReLU).  Rounding points:
       * d feat (pre-ReLU, fp32) is rounded to bf16 only by the matrix-core fc kernels, which run for n >= 1024 (fc_bf16.hip
         fc_tn_kernel / fc_nt_kernel<true>); smaller batches take the fp32 GEMM with the fp32 fc.weight (engine.hip net_backward);
@@ -83,6 +83,15 @@ def impala_backward(p, cache, dfeat_post, feat, rounding=True, dtype=torch.float
     g["embedder.fc.bias"] = dpre.sum(0)
     wfc = _r16(p["embedder.fc.weight"]) if big else p["embedder.fc.weight"]
     gy = r((dq @ wfc).reshape(cache["x3"].shape) * (cache["x3"] > 0))
+    if fs_coef:
+        # + fs_coef * d mean_j max_b tanh(|100 h_bj|) / dh (common/model.py:207): one element per column, the row torch.max picks;
+        # the engine adds it to the stored (bf16) gradient element and rounds again (misc.hip fs_apply_kernel)
+        h = cache["flat"]
+        t, am = torch.max(torch.tanh(torch.abs(h * 100)), 0)
+        cols = torch.arange(h.shape[1])
+        gf = gy.reshape(n, -1).clone()
+        gf[am, cols] = r(gf[am, cols] + (fs_coef * 100.0 / h.shape[1]) * (1 - t * t).to(dtype) * torch.sign(h[am, cols]).to(dtype))
+        gy = gf.reshape(gy.shape)
     ci = lambda shape, w, d: torch.nn.grad.conv2d_input(shape, w, d, padding=1)
     cw = lambda x, w, d: torch.nn.grad.conv2d_weight(x, w.shape, d, padding=1)
     for k in (2, 1, 0):
@@ -131,7 +140,7 @@ def cache_from_engine(frames_u8, acts, feat):
 
 
 def loss_and_grads(params, frames_u8, act, old_logp, old_value, ret, adv, eps_clip=0.2, value_coef=0.5, entropy_coef=0.01,
-                   x_entropy_coef=0.0, rounding=True, dtype=torch.float32, forward=None):
+                   x_entropy_coef=0.0, rounding=True, dtype=torch.float32, forward=None, fs_coef=0.0):
     """One minibatch of PPO.optimize (agents/ppo.py:119-170) with the bf16 engine's rounding points.
     -> (dict of loss terms incl. 'fs', OrderedDict of gradients keyed like the reference's state_dict).
     dtype=torch.float64 accumulates every contraction in fp64 (same rounding points): the distance between that run and the fp32
@@ -148,10 +157,10 @@ def loss_and_grads(params, frames_u8, act, old_logp, old_value, ret, adv, eps_cl
     leaf = feat.clone().requires_grad_(True)
     hp = {k: p[k].clone().requires_grad_(True) for k in ("fc_policy.weight", "fc_policy.bias", "fc_value.weight", "fc_value.bias")}
     lp, value = O.heads(hp, leaf)
-    L = O.ppo_loss(lp, value, act, old_logp, old_value, ret, adv, eps_clip, value_coef, entropy_coef, x_entropy_coef, 1.0)
+    L = O.ppo_loss(lp, value, act, old_logp, old_value, ret, adv, eps_clip, value_coef, entropy_coef, x_entropy_coef, 1.0, fs, fs_coef)
     L["total"].backward()
     with torch.no_grad():
-        g = impala_backward(p, cache, leaf.grad, feat, rounding, dtype)
+        g = impala_backward(p, cache, leaf.grad, feat, rounding, dtype, fs_coef)
         g = OrderedDict((k, v.float()) for k, v in g.items())
     for k, t in hp.items():
         g[k] = t.grad.detach()

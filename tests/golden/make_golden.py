@@ -294,6 +294,39 @@ def g4_loss_grad(arch):
     np.savez_compressed(os.path.join(OUT, f"g4_{arch}_lossgrad.npz"), **out)
 
 
+def g4_feature_sparsity():
+    """G4 with the feature-sparsity term switched on (agents/ppo.py:148-169, common/model.py:207): fs_coef = 0.5.  DARK frames
+    (pixel values 0..3): the network is bias-free at initialisation, so its activations scale with the input and tanh(100 h) stays
+    out of saturation -- with ordinary frames almost every column's maximum sits at tanh = 1 and the term's gradient is exactly 0."""
+    out = {}
+    T, E, A = 4, 8, 15
+    rng = np.random.default_rng(13)
+    r = synth_rollout(rng, T, E, A, "frames")
+    r["frames"] = (r["frames"] % 4).astype(np.uint8)
+    for k, v in r.items():
+        out["in/" + k] = v
+    for tag, fs in (("fs0", 0.0), ("fs", 0.5)):
+        policy = build_impala_policy(6033, A)
+        st = Storage((3, 64, 64), 256, T, E, CPU)
+        fill_storage(st, r, T, E, True)
+        st.compute_estimates(0.999, 0.95, True, True)
+        hp = dict(BASE_HP, epoch=1, n_minibatch=1, mini_batch_size=T * E, grad_clip_norm=1e9, fs_coef=fs)
+        cap = {}
+        torch.manual_seed(5)
+        agent, summary = run_optimize(policy, st, T, E, hp, cap)
+        g = cap["grads"][0]
+        out[f"{tag}/summary"] = np.frombuffer(json.dumps({k: float(v) for k, v in summary.items()}).encode(), np.uint8)
+        out[f"{tag}/grad_stats"] = np.frombuffer(json.dumps(tensor_stats(g)).encode(), np.uint8)
+        out[f"{tag}/grad_total_norm"] = np.float64(np.sqrt(sum((v.astype(np.float64) ** 2).sum() for v in g.values())))
+        for k in g:
+            if g[k].size <= 9216:
+                out[f"{tag}/g/{k}"] = g[k]
+        if tag == "fs":
+            out["adv"] = st.adv_batch.numpy().copy()
+            out["ret"] = st.return_batch.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g4_impala_feature_sparsity.npz"), **out)
+
+
 def g56_optimize(arch):
     """Full PPO.optimize on a stored (T=16,E=8) rollout: G5 (params after optimizer steps 1,2,8,
     accumulation case batch_size/B = 2) and G6 (3-epoch summary + final params)."""
@@ -413,6 +446,10 @@ def g9_recurrent_predict():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                      # regenerate selected fixtures only: python make_golden.py g4_feature_sparsity ...
+        for name in sys.argv[1:]:
+            globals()[name](); print(name, "done")
+        sys.exit(0)
     g1_gae(); print("G1 done")
     g2_perm(); print("G2 done")
     g3_forward(); print("G3 done")
@@ -420,5 +457,6 @@ if __name__ == "__main__":
     for arch in ("mlp", "impala"):
         g4_loss_grad(arch); print("G4", arch, "done")
         g56_optimize(arch); print("G5/6", arch, "done")
+    g4_feature_sparsity(); print("G4 feature sparsity done")
     g8_recurrent(); print("G8 done")
     g9_recurrent_predict(); print("G9 done")

@@ -321,6 +321,30 @@ def test_end_to_end_bf16_against_golden_and_bf16_oracle():
         eng.close()
 
 
+def test_feature_sparsity_gradient_bf16_against_bf16_oracle():
+    """fs_coef = 0.5 in bf16 mode on the dark-frame fixture inputs: forward tensors, teacher-forced backward and noise-floor bounded
+    end-to-end gradients against oracle/ppo_oracle_bf16.py (which is pinned to the reference's fs numbers with its rounding off)."""
+    from mi355 import engine as M, layout
+    from mi355.engine import Engine
+    z = load_npz("g4_impala_feature_sparsity.npz")
+    T, E = 4, 8
+    shapes = layout.impala_param_shapes(15)
+    params = npz_params(load_npz("g3_impala_forward.npz"))
+    eng = Engine("impala", T, E, 15, T * E, precision="bf16")
+    eng.set_params(layout.flatten(shapes, params))
+    for t in range(T + 1):
+        eng.put_obs(t, z["in/frames"][t])
+    for t in range(T):
+        eng.put_step(t, z["in/rew"][t], z["in/done"][t])
+    eng.write_field(M.F_ACT, z["in/act"].astype(np.float32)); eng.write_field(M.F_LOGP, z["in/logp"]); eng.write_field(M.F_VALUE, z["in/val"])
+    eng.compute_estimates(0.999, 0.95, True, True)
+    idx = np.random.default_rng(0).permutation(T * E)
+    eng.minibatch(idx, T * E, eng.hparams(fs_coef=0.5))
+    scal = (z["in/act"][:T], z["in/logp"][:T], z["in/val"][:T], z["ret"], z["adv"])
+    check_bf16_minibatch_against_oracle(eng, shapes, params, z["in/frames"][:T].reshape(T * E, 64, 64, 3), idx, scal, dict(fs_coef=0.5))
+    eng.close()
+
+
 def test_fc_bf16_matrix_core_path_matches_small_batch_path():
     """Minibatches of >= 1024 samples route embedder.fc through the bf16-MFMA NT/TN kernels (fc_bf16.hip); smaller
     ones through the fp32-MFMA GEMM on the same bf16-stored activations.  One 1024-sample minibatch must equal the

@@ -202,6 +202,42 @@ def test_g4_loss_and_grads_golden(arch):
         eng.close()
 
 
+def test_feature_sparsity_gradient_golden():
+    """fs_coef = 0.5 (agents/ppo.py:148-169, common/model.py:207) against what the reference's PPO.optimize produced on dark frames
+    (tanh(100 h) out of saturation; the term is 97 % of this fixture's gradient norm): losses 1e-5, every stored gradient tensor
+    1e-3 of its norm, per-tensor norms 1e-3; fs_coef = 0 on the same inputs as the control."""
+    from mi355 import engine as M, layout
+    z = load_npz("g4_impala_feature_sparsity.npz")
+    T, E, A = 4, 8, 15
+    shapes = shapes_for("impala", A)
+    for tag, fs in (("fs0", 0.0), ("fs", 0.5)):
+        eng = make_engine("impala", T, E, A, T * E)
+        eng.set_params(layout.flatten(shapes, golden_params("impala")))
+        load_rollout(eng, z, T, E)
+        eng.compute_estimates(0.999, 0.95, True, True)
+        np.testing.assert_allclose(eng.read_field(M.F_ADV), z["adv"], rtol=0, atol=2e-6)
+        eng.minibatch(np.random.default_rng(0).permutation(T * E), T * E, eng.hparams(0.2, 0.5, 0.01, 0.0, 1.0, fs))
+        rec = eng.loss_log()[0]
+        ref = npz_json(z, f"{tag}/summary")
+        assert abs(rec[4] - ref["Loss/total"]) < 1e-5 * max(1.0, abs(ref["Loss/total"])) and abs(rec[5] - ref["Loss/feature_sparsity"]) < 1e-5
+        flat_g = eng.get_grads()
+        g = layout.unflatten(shapes, flat_g)
+        for k, (nrm, _) in npz_json(z, f"{tag}/grad_stats").items():
+            mine = float(np.sqrt((g[k].astype(np.float64) ** 2).sum()))
+            assert abs(mine - nrm) < 1e-3 * nrm + 1e-7, (tag, k, mine, nrm)
+        _check_grads(flat_g, shapes, {k[len(tag) + 3:]: z[k] for k in z.files if k.startswith(f"{tag}/g/")})
+        total = float(np.sqrt((flat_g.astype(np.float64) ** 2).sum()))
+        assert abs(total - float(z[f"{tag}/grad_total_norm"])) < 1e-4 * total
+        eng.close()
+    # multi-rank modes need the GLOBAL column maxima before the backward pass: refused, not silently wrong
+    from mi355.engine import EngineError
+    eng = make_engine("impala", T, E, A, T * E)
+    eng.set_multirank(1)
+    with pytest.raises(EngineError):
+        eng.minibatch(np.arange(T * E), T * E, eng.hparams(fs_coef=0.5))
+    eng.close()
+
+
 def test_impala_minibatch_vs_oracle_teacher_forced():
     """B = 192 random-index minibatch out of a (T=8, E=32) rollout: losses and every gradient tensor
     against the oracle (autograd) on identical inputs."""

@@ -242,3 +242,31 @@ def test_bf16_oracle_without_rounding_is_the_fp32_oracle():
     L0, _ = OB.loss_and_grads(params, fr, act, logp, val, ret, adv, rounding=False)
     Lb, gb = OB.loss_and_grads(params, fr, act, logp, val, ret, adv, rounding=True)
     assert 0 < abs(Lb["total"] - L0["total"]) + abs(Lb["value_loss"] - L0["value_loss"]) and abs(Lb["pi_loss"] - L0["pi_loss"]) < 1e-2
+
+
+def test_feature_sparsity_term_matches_reference():
+    """fs_coef != 0 (agents/ppo.py:148-169, common/model.py:207): the fp32 oracle (autograd) and the hand-written backward of the
+    bf16 oracle with rounding off against the reference's losses and gradients on dark frames (tanh out of saturation)."""
+    from oracle import ppo_oracle_bf16 as OB
+    z = load_npz("g4_impala_feature_sparsity.npz")
+    params = npz_params(load_npz("g3_impala_forward.npz"))
+    T, E = 4, 8
+    fr = z["in/frames"][:T].reshape(T * E, 64, 64, 3)
+    f = lambda k: torch.from_numpy(np.ascontiguousarray(z[k]).reshape(-1)[:T * E].astype(np.float32))
+    act, logp, val = f("in/act"), f("in/logp"), torch.from_numpy(z["in/val"][:T].reshape(-1))
+    ret, adv = torch.from_numpy(z["ret"].reshape(-1)), torch.from_numpy(z["adv"].reshape(-1))
+    for tag, fs in (("fs0", 0.0), ("fs", 0.5)):
+        ref = npz_json(z, f"{tag}/summary")
+        ag = O.OraclePPO(params, "impala", T, E, fs_coef=fs)
+        L, g = ag.loss_and_grads(O.frames_to_obs(fr), act, logp, val, ret, adv)
+        Lb, gb = OB.loss_and_grads(params, fr, act, logp, val, ret, adv, rounding=False, fs_coef=fs)
+        for LL in (L, Lb):
+            assert abs(LL["total"] - ref["Loss/total"]) < 2e-6 * max(1, abs(ref["Loss/total"])) and abs(LL["fs"] - ref["Loss/feature_sparsity"]) < 2e-6
+        for gg in (g, gb):
+            for k, (nrm, _) in npz_json(z, f"{tag}/grad_stats").items():
+                assert abs(float((gg[k].double() ** 2).sum().sqrt()) - nrm) < 1e-4 * nrm + 1e-9, (tag, k)
+            for k in z.files:
+                if k.startswith(f"{tag}/g/"):
+                    r = z[k].astype(np.float64); m = gg[k[len(tag) + 3:]].numpy().astype(np.float64)
+                    assert np.sqrt(((m - r) ** 2).sum()) < 1e-4 * np.sqrt((r ** 2).sum()) + 1e-9, (tag, k)
+    assert float(z["fs/grad_total_norm"]) > 10 * float(z["fs0/grad_total_norm"])          # the term dominates this fixture's gradient

@@ -26,8 +26,6 @@ class PPO(BaseAgent):
                  x_entropy_coef=0., normalize_adv=True, normalize_rew=True, use_gae=True, entropy_scaling=None,
                  increasing_lr=False, sparsity_coef=0., fs_coef=0., **kwargs):
         super().__init__(env, policy, logger, storage, device, n_checkpoints, env_valid, storage_valid)
-        if fs_coef != 0.:
-            raise NotImplementedError("fs_coef != 0: the feature-sparsity term is reported but its gradient is not built")
         self.fs_coef = fs_coef
         self.total_timesteps = 0
         self.entropy_scaling = entropy_scaling
@@ -50,6 +48,9 @@ class PPO(BaseAgent):
 
         # ---- data parallel over n_envs: this process owns n_envs envs; the global minibatch spans all ranks
         self.coll = Collective()
+        if fs_coef != 0. and self.coll.active:
+            raise NotImplementedError("fs_coef != 0 on more than one rank: the feature-sparsity term needs the column maxima of the GLOBAL "
+                                      "minibatch before the backward pass (max / arg-min exchange, SURVEY 8(e) C3) -- not built")
         self.n_envs_global = n_envs * self.coll.world
         n_total = n_steps * self.n_envs_global
         batch_size = n_total // n_minibatch

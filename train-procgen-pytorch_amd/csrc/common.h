@@ -185,6 +185,8 @@ void launch_loss_finalize_seg(const LossArgs& a, const SegTab& st, int phase, fl
 void launch_loss_finalize_records(const LossArgs& a, int n_rec, float* stats_base, const float* fs_base, float* log_base, hipStream_t stream);
 // colmax_scratch: 512 x d floats; fs_parts: n_seg x 8 fp64 column-block sums of tanh(100 max_b relu(h))
 void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, double* fs_parts, hipStream_t stream);
+int  fs_groups_per_segment(int n_seg);
+void launch_fs_grad(const void* x, int bf16, int n, int d, const float* part, int G, void* Gd, float fs_coef, float* colmax, int* arg, hipStream_t st);
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st);
 
 void launch_gae(const float* rew, const float* done, const float* value, float* adv, float* ret, int T, int E,

@@ -132,6 +132,7 @@ struct mi_ctx {
     static constexpr int MAX_GROUPS = 4;
     int n_groups; hipStream_t main_stream, gs[MAX_GROUPS]; hipEvent_t ev_fork[MAX_GROUPS], ev_join[MAX_GROUPS];
     bool g_forked[MAX_GROUPS], g_busy[MAX_GROUPS], g_last[MAX_GROUPS], g_dirty[MAX_GROUPS]; unsigned g_ticket[MAX_GROUPS]; bool groups_live;
+    float *fs_colmax, fs_grad_coef; int *fs_arg, fs_G;      // feature-sparsity gradient (fs_coef != 0): column maxima / first arg-max rows of the minibatch
     std::string net_err;        // set by the (void) network program on an unsupported launch; every entry point reports it as -4
 };
 
@@ -304,6 +305,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         HIPC(dalloc(&c->slabs, c->slab_floats));
         HIPC(hipMalloc((void**)&c->d_slab_desc, sizeof(SlabDesc) * 15)); c->slab_desc_n = 0; c->slab_desc_cached_n = -1;
         HIPC(dalloc(&c->fs_scratch, (size_t)MI_MAX_SEG * 128 * 2048));      // (segments x) FS_GROUPS x 2048 partial column maxima (misc.hip)
+        HIPC(dalloc(&c->fs_colmax, (size_t)2048)); HIPC(dalloc(&c->fs_arg, (size_t)2048));
     } else {
         c->obs_bytes_per_env = (size_t)cfg->obs_dim * sizeof(float);
         HIPC(dalloc(&c->obsf, (size_t)(T + 1) * E * cfg->obs_dim));
@@ -358,6 +360,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->h_f_floats = (size_t)4 * (E > 64 ? E : 64);
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
+    c->fs_grad_coef = 0.f; c->fs_G = 0;
+    if (cfg->arch != MI_ARCH_IMPALA) { c->fs_colmax = nullptr; c->fs_arg = nullptr; }
     c->n_groups = 1; c->groups_live = false; c->main_stream = c->stream;
     for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) { c->gs[g] = nullptr; c->ev_fork[g] = c->ev_join[g] = nullptr; c->g_forked[g] = c->g_busy[g] = c->g_last[g] = c->g_dirty[g] = false; c->g_ticket[g] = 0; }
     c->multirank = 0; c->pending_n = -1; c->sal_dc = nullptr; c->sal_dx = nullptr; c->sal_src = nullptr;
@@ -410,6 +414,7 @@ int mi_destroy(mi_ctx* c) {
     hipFree(c->stats_ring); hipFree(c->fs_ring); hipFree(c->fs_parts); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd); hipFree(c->d_done_ctr); hipHostFree(c->h_flag);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
+    if (c->fs_colmax) hipFree(c->fs_colmax); if (c->fs_arg) hipFree(c->fs_arg);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
     hipHostFree(c->h_f); hipHostFree(c->h_i);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -796,6 +801,8 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         launch_fc_dgrad_bf16(c->dfeat, c->fc_wt, c->blk[2].P2, Gout, n, c->stream);
     } else
         linear_dgrad(c, c->dfeat, c->params + c->fc.w_off, c->blk[2].P2, Gout, n, 2048, c->H, c->bf);
+    if (c->fs_grad_coef != 0.f)      // + fs_coef * d(feature sparsity) / d(block3 output): one element per column (launch_fs_grad, misc.hip)
+        launch_fs_grad(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_G, Gout, c->fs_grad_coef, c->fs_colmax, c->fs_arg, c->stream);
     for (int b = 2; b >= 0; --b) {
         Block& k = c->blk[b];
         const ConvLayer* L = &c->convs[b * 5];
@@ -1256,6 +1263,7 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
     ARG(c->pending_n < 0, "previous multirank minibatch not finished");
     { long long tot = 0; for (int k = 0; k < n_seg; ++k) { ARG(seg_n[k] >= 0, "negative segment"); tot += seg_n[k]; } ARG(tot == n, "segments do not add up to n_idx"); }
     const bool batch_terms = hp->x_entropy_coef != 0.f || hp->fs_coef != 0.f;
+    ARG(hp->fs_coef == 0.f || c->multirank == 0, "fs_coef != 0 needs the column maxima over the GLOBAL minibatch: single-rank only (the max / arg-min exchange of SURVEY 8(e) C3 is not built)");
     ARG(n_seg == 1 || (!batch_terms && c->multirank != 1), "several minibatches per call need x_entropy_coef == 0, fs_coef == 0 and multirank mode 0 or 2");
     const int64_t TE = (int64_t)c->T * c->E;
     for (int k = 0; k < n; ++k) ARG(idx[k] >= 0 && idx[k] < TE, "minibatch index out of range");
@@ -1300,7 +1308,9 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
         c->ring_args = a;
         c->log_count += n_seg;
         if (batch_terms) launch_loss_bwd(a, c->stream);
+        if (impala && hp->fs_coef != 0.f && n > 0) { c->fs_grad_coef = hp->fs_coef; c->fs_G = fs_groups_per_segment(n_seg); }
         net_backward(c, src, n);
+        c->fs_grad_coef = 0.f;
         HIPC(hipGetLastError()); NETCHK(c);
         return 0;
     }

@@ -800,6 +800,50 @@ void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colma
     hipLaunchKernelGGL(fs_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)colmax_scratch, FS_GROUPS, d, fs_out);
 }
 
+// Gradient of the feature-sparsity term fs_coef * mean_j max_b tanh(|100 h_bj|) (agents/ppo.py:148-169, common/model.py:207) with
+// respect to the pre-fc features: for every column j the term depends on ONE row, the first one (in minibatch order, torch.max's
+// choice) that attains the column maximum m_j; d/dh = fs_coef * 100 * (1 - tanh(100 m_j)^2) / d there (h > 0: |.| is the identity; a
+// column whose maximum is 0 has gradient 0, abs'(0) = 0).  part: the G x d partial column maxima the metric kernels left behind.
+__global__ __launch_bounds__(256) void fs_colmax_final_kernel(const float* part, int G, int d, float* colmax, int* arg) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d) return;
+    float m = 0.f;
+    for (int g = 0; g < G; ++g) m = fmaxf(m, part[(long long)g * d + j]);
+    colmax[j] = m; arg[j] = 0x7fffffff;
+}
+__global__ __launch_bounds__(256) void fs_argfirst_kernel(const void* x, int bf16, int n, int d, const float* colmax, int* arg) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d) return;
+    const float m = colmax[j];
+    if (!(m > 0.f)) return;
+    int first = 0x7fffffff;
+    for (int b = blockIdx.y; b < n; b += gridDim.y) {
+        const long long o = (long long)b * d + j;
+        const float v = bf16 ? __uint_as_float(((unsigned)((const unsigned short*)x)[o]) << 16) : ((const float*)x)[o];
+        if (v == m && b < first) first = b;
+    }
+    if (first != 0x7fffffff) atomicMin(arg + j, first);
+}
+__global__ __launch_bounds__(256) void fs_apply_kernel(void* G, int bf16, int d, const float* colmax, const int* arg, float scale) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d) return;
+    const int b = arg[j];
+    if (b == 0x7fffffff) return;
+    const float t = tanhf(fabsf(colmax[j] * 100.f)), g = scale * (1.f - t * t);
+    const long long o = (long long)b * d + j;
+    if (bf16) {
+        unsigned short* p = (unsigned short*)G + o;
+        *p = f2bf_g(__uint_as_float(((unsigned)*p) << 16) + g);
+    } else ((float*)G)[o] += g;
+}
+// x: block3's output before the ReLU [n][d] (fp32 / bf16); part: [G][d] partial column maxima of relu(x); Gd: d loss / d x [n][d], updated in place
+void launch_fs_grad(const void* x, int bf16, int n, int d, const float* part, int G, void* Gd, float fs_coef, float* colmax, int* arg, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fs_colmax_final_kernel, dim3((d + 255) / 256), dim3(256), 0, st, part, G, d, colmax, arg);
+    hipLaunchKernelGGL(fs_argfirst_kernel, dim3((d + 255) / 256, n < 64 ? n : 64), dim3(256), 0, st, x, bf16, n, d, (const float*)colmax, arg);
+    hipLaunchKernelGGL(fs_apply_kernel, dim3((d + 255) / 256), dim3(256), 0, st, Gd, bf16, d, (const float*)colmax, (const int*)arg, fs_coef * 100.f / (float)d);
+}
+
 // ------------------------------------------------------------------------------------------ GAE scan
 // Storage.compute_estimates (common/storage.py:56-77).  One thread per env (coalesced over E),
 // serial over T; fp contraction off so every operation rounds exactly like the reference's
