@@ -444,6 +444,57 @@ def g9_recurrent_predict():
     np.savez_compressed(os.path.join(OUT, "g9_recurrent_predict.npz"), **out)
 
 
+def g10_logger():
+    """Logger.feed / dump (common/logger.py:98-174) and Storage.fetch_log_data (common/storage.py:130-162) over three iterations of
+    a (T=64, E=8) reward / done / info stream, training + validation: every CSV column of every dumped row (wall_time aside).
+    Episodes run across iteration boundaries, one env never finishes, one episode is exactly max_steps long (timeout flag), and
+    more than 40 episodes finish (the 40-deep deques roll over).  A second run feeds rewards / dones WITHOUT info dicts (the
+    cartpole-style path: rew_batch / done_batch tensors are logged)."""
+    import tempfile
+    from common.logger import Logger
+    T, E, K = 64, 8, 3
+    rng = np.random.default_rng(31)
+    out = {}
+    for variant in ("info", "plain"):
+        logdir = tempfile.mkdtemp()
+        logger = Logger(E, logdir)
+        logger.max_steps = 37
+        st, stv = Storage((9,), 64, T, E, CPU), Storage((9,), 64, T, E, CPU)
+        rows = []
+        for k in range(K):
+            streams = []
+            for which, storage in (("t", st), ("v", stv)):
+                rew = rng.standard_normal((T, E)).astype(np.float32)
+                raw = (rng.integers(0, 3, size=(T, E)) * 5).astype(np.float32)           # env_reward: what Procgen reports (0 / 5 / 10)
+                done = rng.random((T, E)) < (0.09 if which == "t" else 0.05)
+                done[:, 3] = False                                                         # an env that never finishes
+                if which == "t" and k == 0:
+                    done[:, 5] = False; done[36, 5] = True                                 # first episode of env 5: exactly max_steps = 37 steps
+                seeds = rng.integers(0, 6, size=(T, E))
+                out[f"{variant}/{k}/{which}/rew"], out[f"{variant}/{k}/{which}/raw"] = rew, raw
+                out[f"{variant}/{k}/{which}/done"], out[f"{variant}/{k}/{which}/seed"] = done, seeds
+                z9, h = np.zeros((E, 9), np.float32), np.zeros((E, 64), np.float32)
+                for t in range(T):
+                    info = [{"env_reward": raw[t, e], "prev_level_seed": int(seeds[t, e])} for e in range(E)] if variant == "info" else [{} for _ in range(E)]
+                    storage.store(z9, h, np.zeros(E), rew[t], done[t], info, np.zeros(E), np.zeros(E))
+                storage.store_last(z9, h, np.zeros(E))
+                if variant == "plain":
+                    # no 'prev_level_seed': the reference's fetch_log_data averages an empty list (nan + warning)
+                    pass
+                streams.append(storage.fetch_log_data())
+            (rb, db, tm), (rbv, dbv, tmv) = streams
+            out[f"{variant}/{k}/fetch_t_rew"], out[f"{variant}/{k}/fetch_t_done"] = np.asarray(rb, np.float64), np.asarray(db, np.float64)
+            logger.feed(rb, db, tm, rbv, dbv, tmv)
+            summary = {'Loss/pi': 0.1 * k, 'Loss/v': -0.2, 'Loss/entropy': 2.7, 'Loss/x_entropy': 0.0, 'Loss/atn_entropy': float("nan"),
+                       'Loss/atn_entropy2': float("nan"), 'Loss/sparsity': float("nan"), 'Loss/feature_sparsity': 0.8, 'Loss/total': 1.5 - k}
+            logger.dump(summary, 5e-4 * (1 - k / K))
+            rows.append([float(x) if x is not None else None for x in logger.log.loc[len(logger.log) - 1].tolist()])
+        out[f"{variant}/rows"] = np.frombuffer(json.dumps(rows).encode(), np.uint8)
+        out[f"{variant}/columns"] = np.frombuffer(json.dumps(list(logger.log.columns)).encode(), np.uint8)
+        out[f"{variant}/csv"] = np.frombuffer(open(os.path.join(logdir, "log-append.csv")).read().encode(), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "g10_logger.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                      # regenerate selected fixtures only: python make_golden.py g4_feature_sparsity ...
@@ -458,5 +509,6 @@ if __name__ == "__main__":
         g4_loss_grad(arch); print("G4", arch, "done")
         g56_optimize(arch); print("G5/6", arch, "done")
     g4_feature_sparsity(); print("G4 feature sparsity done")
+    g10_logger(); print("G10 logger done")
     g8_recurrent(); print("G8 done")
     g9_recurrent_predict(); print("G9 done")

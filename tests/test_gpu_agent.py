@@ -284,6 +284,35 @@ def test_train_through_the_procgen_frame_source(tmp_path):
     assert state["t"] == 3 * T * E and state["reward_norm"]["count"] == pytest.approx(1e-4 + 3 * T * E) and state["reward_norm"]["var"] > 0
 
 
+def test_train_cli_runs_and_resumes(tmp_path):
+    """`python train.py` end to end (reference CLI, train.py:303-326): default hyper-parameter set name resolves, synthetic env in two
+    pipelined groups + a validation env, two iterations, checkpoint in the reference's format; then `--model_file auto` finds that
+    run directory, loads the newest checkpoint (weights, Adam state, step counter) and continues in it.  --detect_nan on."""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG, ROOT]))
+    base = [sys.executable, os.path.join(PKG, "train.py"), "--exp_name", "cli", "--env_name", "synthetic", "--param_name", "debug",
+            "--n_envs", "8", "--n_steps", "16", "--mini_batch_size", "32", "--seed", "3", "--detect_nan", "--precision", "bf16"]
+    r = subprocess.run(base + ["--num_timesteps", "250", "--num_checkpoints", "1"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    runs = os.listdir(tmp_path / "logs" / "train" / "synthetic" / "cli")
+    assert len(runs) == 1 and runs[0].endswith("__seed_3")
+    rd = tmp_path / "logs" / "train" / "synthetic" / "cli" / runs[0]
+    files = set(os.listdir(rd))
+    assert {"hyperparameters.npy", "config.npy", "log-append.csv", "model_256.pth"} <= files, files
+    ck = torch.load(rd / "model_256.pth", map_location="cpu", weights_only=True)
+    assert ck["t"] == 256 and len(ck["model_state_dict"]) == 36 and float(ck["optimizer_state_dict"]["state"][0]["step"]) == 8.0      # 2 iterations x 4 minibatches
+    assert ck["model_state_dict"]["fc_policy.weight"].shape == (9, 256)          # reduce_duplicate_actions default: 9 actions
+    rows = open(rd / "log-append.csv").read().strip().splitlines()
+    assert len(rows) == 3 and rows[0].startswith("timesteps,wall_time,num_episodes,max_episode_rewards")
+    r = subprocess.run(base + ["--num_timesteps", "500", "--num_checkpoints", "1", "--model_file", "auto"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Loading agent from" in r.stdout and "model_256.pth" in r.stdout
+    assert os.listdir(tmp_path / "logs" / "train" / "synthetic" / "cli") == runs                 # same run directory reused
+    ck2 = torch.load(rd / "model_512.pth", map_location="cpu", weights_only=True)
+    assert ck2["t"] == 512 and float(ck2["optimizer_state_dict"]["state"][0]["step"]) == 16.0    # continued, not restarted
+    assert len(open(rd / "log-append.csv").read().strip().splitlines()) == 5
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_accumulated_minibatches_in_one_pass_equal_one_by_one(precision):
     """Gradient accumulation (batch_size / mini_batch_size = 4 minibatches summed per optimizer step, agents/ppo.py:155-177) taken

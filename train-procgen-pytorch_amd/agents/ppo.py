@@ -43,6 +43,9 @@ class PPO(BaseAgent):
         self.adjust_lr = adjust_lr_grok if increasing_lr else adjust_lr
         self.seed = int(kwargs.get("seed", 0))
         self.merge_accumulation = bool(kwargs.get("merge_accumulation", True))      # (new) see optimize()
+        # train.py --detect_nan (reference: autograd anomaly mode + a NaN hook on every module's output, train.py:123-124,234-250):
+        # here the policy outputs of every rollout step, every minibatch's loss record and every gradient norm are checked
+        self.detect_nan = bool(kwargs.get("detect_nan", False))
         # activation storage of the IMPALA path: "fp32" (parity mode) or "bf16" (BASELINE config 3)
         self.precision = kwargs.get("precision", "fp32") if policy.arch == "impala" else "fp32"
 
@@ -116,6 +119,8 @@ class PPO(BaseAgent):
         if rec:
             engine.rec_state(hidden_state, done)
         act, logp, value = engine.rollout_step(t, seed=self.seed * 1000003 + self._iter)
+        if self.detect_nan and not (np.isfinite(value).all() and np.isfinite(logp).all()):
+            raise RuntimeError(f"Found NaN / Inf in the policy outputs of rollout step {t}")
         storage.note_predicted(t, obs, act, logp, value)
         return act, logp, value, (engine.get_hidden() if rec else hidden_state)
 
@@ -200,12 +205,17 @@ class PPO(BaseAgent):
                 if coll.active:
                     with torch.cuda.stream(self._tstream):
                         coll.allreduce_sum_(self._grads_t)   # ONE collective per optimizer step: the flat gradient
-                self.optimizer.step(self.grad_clip_norm)
+                gn = self.optimizer.step(self.grad_clip_norm, want_norm=self.detect_nan)
+                if self.detect_nan and not np.isfinite(gn):
+                    raise RuntimeError(f"Found NaN / Inf in the gradient norm of optimizer step {self.optimizer.step_count}: {gn}")
             elif deferred:                                   # ("log", n): the statistics ring, once per optimize()
                 with torch.cuda.stream(self._tstream):
                     coll.allreduce_sum_(self._ring_t[:32 * op[1]])
                 eng.loss_log_finalize()
         log = eng.loss_log(reset=True)
+        if self.detect_nan and not np.isfinite(log[:, :5]).all():
+            bad = np.argwhere(~np.isfinite(log[:, :5]))
+            raise RuntimeError(f"Found NaN / Inf in the loss terms (minibatch, term) {bad[:8].tolist()} of this update")
         nan = float("nan")
         fs = float(np.mean(log[:, 5])) if self.policy.arch == "impala" else nan
         return {'Loss/pi': float(np.mean(-log[:, 0])), 'Loss/v': float(np.mean(-log[:, 1])),

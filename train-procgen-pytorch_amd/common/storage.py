@@ -31,6 +31,9 @@ class Storage:
         self.device = device
         self.engine = None
         self.arch = "impala" if len(self.obs_shape) == 3 else "mlp"
+        # host mirrors of reward / done: what Logger and fetch_log_data read (pinned once an engine is attached)
+        self._rew = np.zeros((num_steps, num_envs), np.float32)
+        self._done = np.zeros((num_steps, num_envs), np.float32)
         self.reset()
 
     # ------------------------------------------------------------------ engine plumbing
