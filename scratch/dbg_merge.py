@@ -30,9 +30,9 @@ for merge in (False, True):
     torch.manual_seed(5)
     rec = []
     orig = agent.optimizer.step
-    def step(clip, orig=orig, eng=eng, rec=rec):
+    def step(clip, orig=orig, eng=eng, rec=rec, **kw):
         g = eng.get_grads()
-        orig(clip)
+        orig(clip, **kw)
         rec.append((g, eng.get_params()))
     agent.optimizer.step = step
     agent.optimize()

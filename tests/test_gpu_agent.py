@@ -342,7 +342,7 @@ def test_accumulated_minibatches_in_one_pass_equal_one_by_one(precision):
         eng.minibatch = lambda idx, ng, hp: (calls.append([len(idx)]), orig_one(idx, ng, hp))[1]
         steps = []
         orig_step = agent.optimizer.step
-        agent.optimizer.step = lambda clip, o=orig_step, e=eng, r=steps: (r.append(e.get_grads()), o(clip), r.append(e.get_params()))[1]
+        agent.optimizer.step = lambda clip, o=orig_step, e=eng, r=steps, **kw: (r.append(e.get_grads()), o(clip, **kw), r.append(e.get_params()))[1]
         summary = agent.optimize()                           # 16 minibatches, 4 optimizer steps
         out.append((steps, summary, calls))
     (t0, s0, c0), (t1, s1, c1) = out
