@@ -18,6 +18,9 @@ import os
 import sys
 import time
 
+if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:       # before anything initialises HIP: RCCL needs dmabuf IPC on this driver
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "train-procgen-pytorch_amd")
 for p in (ROOT, PKG):
@@ -33,39 +36,65 @@ MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: matrix fp32 (v_mfma_f32_*_f3
 MFMA_BF16_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: bf16 MFMA, dense (the 5 PF headline is 2:1 sparse)
 
 
-def cpu_baseline(T, n_samples, threads):
-    """The CPU oracle (oracle/ppo_oracle.py, a restatement of the reference's PyTorch path) timed on the host
-    cores on a bounded sample and extrapolated with the iteration's own sample counts."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(hp, E, A, t_sample, threads):
+    """The CPU oracle (oracle/ppo_oracle.py, the restatement of the reference's PyTorch path, SURVEY 8(d) "CPU baseline") on the
+    host cores, with the REFERENCE's data path: observations converted to fp32 NCHW on the host and kept in a (T+1,E,3,64,64) fp32
+    host storage, one forward + sample per rollout step on the stored step, GAE on the host, then a full epoch of minibatches each
+    GATHERED BY INDEX from that storage (common/storage.py:112-128), forward / backward / clip / Adam.  Bounded sample: t_sample
+    rollout steps of the E envs instead of T = 256 (everything scales linearly in T; minibatch = N_sample / 8 keeps 8 optimizer
+    steps per epoch); one epoch is timed and counted `epoch` times."""
     from oracle import ppo_oracle as O
     from common.model import ImpalaModel
     from common.policy import CategoricalPolicy
     torch.set_num_threads(threads)
     torch.manual_seed(6033)
-    pol = CategoricalPolicy(ImpalaModel(3), False, 15)
+    pol = CategoricalPolicy(ImpalaModel(3), False, A)
     params = {k: v.detach().numpy().copy() for k, v in pol.state_dict().items()}
     rng = np.random.default_rng(0)
-    frames = rng.integers(0, 256, size=(n_samples, 64, 64, 3), dtype=np.uint8)
-    ag = O.OraclePPO(params, "impala", 1, n_samples, learning_rate=5e-4)
-    obs = O.frames_to_obs(frames)
-    f = lambda x: torch.from_numpy(x.astype(np.float32))
-    act, logp = f(rng.integers(0, 15, n_samples)), f(np.full(n_samples, np.log(1 / 15)))
-    val, ret, adv = f(rng.standard_normal(n_samples)), f(rng.standard_normal(n_samples)), f(rng.standard_normal(n_samples))
+    T = t_sample
+    frames = rng.integers(0, 256, size=(T + 1, E, 64, 64, 3), dtype=np.uint8)
     p = {k: torch.from_numpy(v) for k, v in params.items()}
     with torch.no_grad():
-        O.policy_forward(p, "impala", obs[:64])
+        O.policy_forward(p, "impala", O.frames_to_obs(frames[0, :32]))                      # warm-up (thread pool, allocator)
+    obs_store = torch.zeros(T + 1, E, 3, 64, 64)                                            # Storage.obs_batch (common/storage.py:21)
+    act, logp = torch.zeros(T, E), torch.zeros(T, E)
+    val = torch.zeros(T + 1, E)
+    rew = torch.from_numpy(rng.standard_normal((T, E)).astype(np.float32))
+    done = torch.from_numpy((rng.random((T, E)) < 0.01).astype(np.float32))
     t0 = time.time()
     with torch.no_grad():
-        O.policy_forward(p, "impala", obs)
-    t_fwd = (time.time() - t0) / n_samples
+        for t in range(T + 1):                                                              # PPO.predict + Storage.store (agents/ppo.py:225-236)
+            obs_store[t] = O.frames_to_obs(frames[t])
+            lp, v, _ = O.policy_forward(p, "impala", obs_store[t])
+            val[t] = v
+            if t < T:
+                a, l = O.sample_actions(lp, torch.from_numpy(rng.random(E).astype(np.float32)))
+                act[t], logp[t] = a.float(), l
+    t_roll = time.time() - t0
     t0 = time.time()
-    _, g = ag.loss_and_grads(obs, act, logp, val, ret, adv)
-    O.clip_grad_norm(g, 0.5)
-    O.adam_step(ag.p, g, ag.m, ag.v, 1, 5e-4)
-    t_train = (time.time() - t0) / n_samples
-    per_step = t_fwd * (1 + 1.0 / T) + 3 * t_train
-    return dict(value=1.0 / per_step, unit="env steps/s", cores=threads, kind="port",
-                sample=f"{n_samples}-frame rollout forward + one {n_samples}-sample fwd/bwd/clip/Adam minibatch of the CPU "
-                       f"oracle, extrapolated to (1+1/T) forwards + 3 update passes per env step")
+    adv, ret = O.compute_estimates(rew, done, val, hp["gamma"], hp["lmbda"], hp["use_gae"], hp["normalize_adv"])
+    t_gae = time.time() - t0
+    N = T * E
+    ag = O.OraclePPO(params, "impala", T, E, epoch=1, n_minibatch=8, mini_batch_size=N // 8, learning_rate=hp["learning_rate"],
+                     gamma=hp["gamma"], lmbda=hp["lmbda"])
+    t0 = time.time()
+    ag.optimize(dict(obs=obs_store, act=act, logp=logp, val=val, ret=ret, adv=adv))         # 1 epoch: randperm + 8 gathered minibatches
+    t_epoch = time.time() - t0
+    total = t_roll + t_gae + hp["epoch"] * t_epoch
+    return dict(value=N / total, unit="env steps/s", cores=threads, kind="port", cpu=cpu_model(),
+                sample=f"{T} rollout steps x {E} envs ({N} env steps of the {hp['n_steps']} x {E} iteration): host fp32 (T+1,E,3,64,64) storage, "
+                       f"{T + 1} forward+sample passes {t_roll:.1f} s, GAE {t_gae * 1e3:.0f} ms, one epoch of 8 index-gathered minibatches of {N // 8} "
+                       f"(forward, backward, clip, Adam) {t_epoch:.1f} s, counted {hp['epoch']}x")
 
 
 def rocprof_name(cls, precision):
@@ -157,7 +186,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--param_name", default="hard-500")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=16, help="rollout steps (of all E envs) the CPU baseline leg runs")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
                     help="activation storage: fp32 = parity mode; bf16 = BASELINE config 3 (bf16 storage + bf16 MFMA fwd/dgrad)")
@@ -185,7 +214,6 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -326,7 +354,7 @@ def main():
                "kernels": sorted(prof, key=lambda r: -r["ms"])[:24],
                "loss_total": summary["Loss/total"]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T, args.cpu_sample, args.cpu_threads or host_cores())
+            out["cpu_baseline"] = cpu_baseline(hp, E, A, args.cpu_sample, args.cpu_threads or host_cores())
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

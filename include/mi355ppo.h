@@ -158,8 +158,26 @@ int mi_minibatch_multi(mi_ctx* ctx, const int64_t* idx, int32_t n_idx, const int
 int mi_optimizer_step(mi_ctx* ctx, float lr, float max_grad_norm, int32_t adam_step, float* grad_norm_out);
 int mi_loss_log_read(mi_ctx* ctx, float* out, int32_t max_records, int32_t* n_records, int32_t reset);
 
-/* ---- raw device pointers for collectives issued by the host side (RCCL through torch.distributed) */
+/* ---- data-parallel collectives inside the boundary: RCCL over xGMI, one communicator per context (SURVEY 8(b) mi_allreduce_grads,
+ *      8(e) C1-C3).  Rank 0 obtains a 128-byte id (mi_comm_unique_id) and hands it to every rank by any host channel
+ *      (mi355/dist.py uses torch.distributed.broadcast_object_list); every rank then calls mi_comm_init(id, rank, world).
+ *      C1: the flat gradient is summed over the ranks once per optimizer step.  mi_allreduce_arm() before the LAST accumulated
+ *      mi_minibatch* of a step makes that backward pass hand its gradient regions to a side stream as they become final (embedder.fc +
+ *      heads -- 84 % of the bytes -- right after the first launches of the backward pass, the conv layers after the slab reduction), so
+ *      the exchange overlaps the backward pass; mi_allreduce_grads() sends whatever an armed pass has not sent (the whole buffer
+ *      when nothing was armed).  mi_optimizer_step waits for the exchange on the device (no host sync).
+ *      C2: mi_adv_normalize_global = advantage statistics {count, mean, M2} all-gathered in fp64, merged and applied on the device.
+ *      C3 / logging: mi_allreduce_buffer sums the first n floats of MI_PTR_LOSS_STATS / MI_PTR_STATS_RING on the context's stream. */
 enum { MI_PTR_GRADS = 0, MI_PTR_LOSS_STATS = 1, MI_PTR_PARAMS = 2, MI_PTR_STATS_RING = 3 };
+int mi_comm_unique_id(void* out128, size_t bytes);
+int mi_comm_init(mi_ctx* ctx, const void* id128, size_t bytes, int32_t rank, int32_t world);
+int mi_comm_destroy(mi_ctx* ctx);
+int mi_allreduce_arm(mi_ctx* ctx);
+int mi_allreduce_grads(mi_ctx* ctx);
+int mi_allreduce_buffer(mi_ctx* ctx, int32_t which, int64_t n_floats);
+int mi_adv_normalize_global(mi_ctx* ctx);
+
+/* ---- raw device pointers for collectives issued by the host side (the gloo path of the CPU tests; RCCL runs inside the library, above) */
 int mi_device_ptr(mi_ctx* ctx, int32_t which, void** ptr, int64_t* n_floats);
 /* two-phase loss finalisation for multi-rank runs (phase 2 after the cross-rank sum of the stats) */
 int mi_set_multirank(mi_ctx* ctx, int32_t enabled);   /* 0 single rank; 1 stats all-reduced per minibatch (mi_minibatch_finish); 2 deferred */

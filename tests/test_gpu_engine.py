@@ -457,6 +457,58 @@ def test_pipelined_rollout_groups_equal_serial_steps(arch, precision, groups):
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("arch", ["impala", "mlp"])
+def test_rccl_collectives_behind_the_c_abi_world_1(arch):
+    """mi_comm_init / mi_allreduce_arm / mi_allreduce_grads / mi_allreduce_buffer / mi_adv_normalize_global with a ONE-rank RCCL
+    communicator (what a one-GPU box can run: RCCL refuses two ranks on one device): every collective is the identity, so the
+    armed, overlapped update -- gradient regions handed to the side stream during the backward pass, optimizer step waiting on the
+    exchange's event -- must be bit-equal to the plain one.  (N > 1 is covered on the CPU by the gloo tests of the same schedule and
+    measured by the driver's multi-GPU bench; it has not run on hardware in this build container.)"""
+    from mi355 import engine as M, layout
+    T, E, A, B = 4, 16, (15 if arch == "impala" else 2), 64
+    rng = np.random.default_rng(21)
+    obs = rng.integers(0, 256, size=(T + 1, E, 64, 64, 3), dtype=np.uint8) if arch == "impala" else rng.standard_normal((T + 1, E, 9)).astype(np.float32)
+    act = rng.integers(0, A, (T, E)); logp = (np.log(1 / A) + 0.2 * rng.standard_normal((T, E))).astype(np.float32)
+    val = rng.standard_normal((T + 1, E)).astype(np.float32); rew = rng.standard_normal((T, E)).astype(np.float32)
+    done = (rng.random((T, E)) < 0.2).astype(np.float32)
+    flat = layout.flatten(shapes_for(arch, A), golden_params(arch))
+    out = []
+    for native in (False, True):
+        eng = make_engine(arch, T, E, A, B)
+        eng.set_params(flat)
+        for t in range(T + 1):
+            eng.put_obs(t, obs[t])
+        eng.write_field(M.F_ACT, act.astype(np.float32)); eng.write_field(M.F_LOGP, logp); eng.write_field(M.F_VALUE, val)
+        eng.write_field(M.F_REW, rew); eng.write_field(M.F_DONE, done)
+        if native:
+            eng.comm_init(eng.comm_unique_id(), 0, 1)
+            eng.compute_estimates(0.999, 0.95, True, False)
+            eng.adv_normalize_global()
+        else:
+            eng.compute_estimates(0.999, 0.95, True, True)
+        adv = eng.read_field(M.F_ADV)
+        idx = rng.permutation(T * E) if not out else out[0][4]
+        hp = eng.hparams()
+        eng.minibatch(idx[:32], 64, hp)                      # two accumulated minibatches, the second one armed
+        if native:
+            eng.allreduce_arm()
+        eng.minibatch(idx[32:], 64, hp)
+        if native:
+            eng.allreduce_grads()                            # nothing left to send
+            eng.allreduce_buffer(M.PTR_STATS_RING, 64)
+        g = eng.get_grads()
+        gn = eng.optimizer_step(5e-4, 0.5, 1, want_norm=True)
+        if native:                                           # a step without arming: the whole buffer goes at mi_allreduce_grads
+            eng.minibatch(idx[:32], 32, hp); eng.allreduce_grads(); eng.optimizer_step(5e-4, 0.5, 2)
+        else:
+            eng.minibatch(idx[:32], 32, hp); eng.optimizer_step(5e-4, 0.5, 2)
+        out.append((adv, g, gn, eng.get_params(), idx, eng.loss_log()))
+        eng.close()
+    a, b = out
+    np.testing.assert_allclose(b[0], a[0], rtol=0, atol=2e-6)          # merged-statistics path vs the fused single-rank kernel
+    assert np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]) and np.array_equal(a[5], b[5])
+
+
 def test_contexts_do_not_share_workspaces():
     """Two contexts live at once (PPO builds a training and a validation engine), the second destroyed first: the survivor's
     minibatch + optimizer step must be bit-equal to a run where it was alone.  (Split-K, column-sum and grad-norm workspaces were

@@ -15,6 +15,17 @@ from common.misc_util import adjust_lr, adjust_lr_grok
 from common.model import as_device_obs
 from mi355.dist import Collective, DevicePointerTensor, update_plan
 from mi355.engine import Engine, PTR_GRADS, PTR_LOSS_STATS, PTR_STATS_RING
+
+
+def _with_next(it):
+    """(item, next item or None) pairs: the update schedule needs one operation of look-ahead to arm the overlapped gradient exchange."""
+    it = iter(it)
+    prev = next(it, None)
+    for cur in it:
+        yield prev, cur
+        prev = cur
+    if prev is not None:
+        yield prev, None
 from mi355.optim import DeviceAdam
 from .base_agent import BaseAgent
 
@@ -87,6 +98,9 @@ class PPO(BaseAgent):
             policy.attach_aux_engine(self.engine_valid)          # frozen GRU weights, now and after load_state_dict
         self.optimizer = DeviceAdam(policy, self.engine, learning_rate, eps=1e-5)
         self._grads_t = self._stats_t = self._ring_t = None
+        # collectives: RCCL inside the library when the process group is "nccl" (one GPU per rank); torch.distributed on aliased
+        # buffers otherwise (gloo: CPU tests / rehearsal)
+        self._native = self.coll.attach_native(self.engine) if self.coll.active else False
         if self.coll.active:
             self.engine.set_multirank(True)
             gp, gn = self.engine.device_ptr(PTR_GRADS)
@@ -189,28 +203,44 @@ class PPO(BaseAgent):
             for _ in range(self.epoch):
                 yield from self.storage.minibatch_index_stream(self.mini_batch_size, recurrent, self.n_envs_global)
 
-        for op in update_plan(chunks(), coll.rank, coll.world, self.n_envs_global, grad_accumulation_steps, merge,
-                              coll.active and not deferred, eng.max_batch):
+        native = self._native
+        plan = update_plan(chunks(), coll.rank, coll.world, self.n_envs_global, grad_accumulation_steps, merge,
+                           coll.active and not deferred, eng.max_batch)
+        for op, nxt in _with_next(plan):
             if op[0] == "minibatch":
                 _, local, seg_n, n_global = op
+                # the LAST pass before an optimizer step hands its gradient regions to the side stream as they become final
+                # (mi_allreduce_arm); with a per-minibatch statistics exchange the backward pass runs inside minibatch_finish (below)
+                if native and nxt is not None and nxt[0] == "step":
+                    eng.allreduce_arm()
                 if len(seg_n) > 1 or merge:
                     eng.minibatch_multi(local, seg_n, n_global, hp)
                 else:
                     eng.minibatch(local, n_global, hp)
             elif op[0] == "stats":
-                with torch.cuda.stream(self._tstream):
-                    coll.allreduce_sum_(self._stats_t)       # 32 floats: loss sums + mean action probabilities
+                if native:
+                    eng.allreduce_buffer(PTR_LOSS_STATS, 32)
+                else:
+                    with torch.cuda.stream(self._tstream):
+                        coll.allreduce_sum_(self._stats_t)       # 32 floats: loss sums + mean action probabilities
+                if native and nxt is not None and nxt[0] == "step":
+                    eng.allreduce_arm()
                 eng.minibatch_finish()
             elif op[0] == "step":
-                if coll.active:
+                if native:
+                    eng.allreduce_grads()                    # whatever the armed pass has not sent yet (normally nothing)
+                elif coll.active:
                     with torch.cuda.stream(self._tstream):
                         coll.allreduce_sum_(self._grads_t)   # ONE collective per optimizer step: the flat gradient
                 gn = self.optimizer.step(self.grad_clip_norm, want_norm=self.detect_nan)
                 if self.detect_nan and not np.isfinite(gn):
                     raise RuntimeError(f"Found NaN / Inf in the gradient norm of optimizer step {self.optimizer.step_count}: {gn}")
             elif deferred:                                   # ("log", n): the statistics ring, once per optimize()
-                with torch.cuda.stream(self._tstream):
-                    coll.allreduce_sum_(self._ring_t[:32 * op[1]])
+                if native:
+                    eng.allreduce_buffer(PTR_STATS_RING, 32 * op[1])
+                else:
+                    with torch.cuda.stream(self._tstream):
+                        coll.allreduce_sum_(self._ring_t[:32 * op[1]])
                 eng.loss_log_finalize()
         log = eng.loss_log(reset=True)
         if self.detect_nan and not np.isfinite(log[:, :5]).all():

@@ -122,7 +122,10 @@ class Storage:
             return
         from mi355.dist import merge_adv_stats
         eng.compute_estimates(gamma, lmbda, use_gae, False)
-        eng.adv_apply(merge_adv_stats(collective.allgather_f64(eng.adv_stats())))
+        if getattr(eng, "comm_world", 0) > 1:
+            eng.adv_normalize_global()                       # RCCL inside the library: all-gather + Chan merge + apply on the device
+        else:
+            eng.adv_apply(merge_adv_stats(collective.allgather_f64(eng.adv_stats())))
 
     # ------------------------------------------------------------------ index streams (bit-exact with the reference)
     def minibatch_index_stream(self, mini_batch_size=None, recurrent=False, n_envs_global=None):

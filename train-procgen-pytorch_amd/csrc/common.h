@@ -193,6 +193,7 @@ void launch_gae(const float* rew, const float* done, const float* value, float* 
                 float gamma, float lmbda, int use_gae, hipStream_t st);
 void launch_advnorm_stats(const float* adv, int n, double* stats3, hipStream_t st);   // stats3 = {count, mean, M2}
 void launch_advnorm_apply(float* adv, int n, const double* stats3, hipStream_t st);
+void launch_advnorm_merge(const double* all, int R, double* stats3, hipStream_t st);   // all: R x {count, mean, M2}
 
 void launch_sample(const float* hout, int n, int A, const float* u, unsigned long long seed, unsigned long long ctr,
                    int32_t* act, float* logp, float* value, hipStream_t st);

@@ -10,6 +10,7 @@
 // update (common/storage.py:112-128); here the minibatch gather is an index read inside the first conv.
 #include "common.h"
 #include "../../include/mi355ppo.h"
+#include <rccl/rccl.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -27,11 +28,17 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (e_ != hipSuccess)                                                                            \
             return fail(-2, std::string(#x) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
     } while (0)
+#define NCCLC(x)                                                                                         \
+    do {                                                                                                 \
+        ncclResult_t r_ = (x);                                                                           \
+        if (r_ != ncclSuccess) return fail(-5, std::string(#x) + ": " + ncclGetErrorString(r_) + " @" + std::to_string(__LINE__)); \
+    } while (0)
 #define ARG(c, msg) do { if (!(c)) return fail(-1, std::string("invalid argument: ") + msg); } while (0)
 #define NETCHK(c) do { if (!(c)->net_err.empty()) { std::string m_ = (c)->net_err; (c)->net_err.clear(); return fail(-4, m_); } } while (0)
 
 struct mi_ctx;
 static int join_groups(mi_ctx* c);
+extern "C" int mi_comm_destroy(mi_ctx* c);
 // every entry point that issues work on the context's main stream first orders it behind the env-group streams of a pipelined rollout
 #define JOIN(c) do { if ((c)->groups_live) { int r_ = join_groups(c); if (r_) return r_; } } while (0)
 
@@ -133,6 +140,9 @@ struct mi_ctx {
     int n_groups; hipStream_t main_stream, gs[MAX_GROUPS]; hipEvent_t ev_fork[MAX_GROUPS], ev_join[MAX_GROUPS];
     bool g_forked[MAX_GROUPS], g_busy[MAX_GROUPS], g_last[MAX_GROUPS], g_dirty[MAX_GROUPS]; unsigned g_ticket[MAX_GROUPS]; bool groups_live;
     float *fs_colmax, fs_grad_coef; int *fs_arg, fs_G;      // feature-sparsity gradient (fs_coef != 0): column maxima / first arg-max rows of the minibatch
+    // data-parallel collectives (RCCL over xGMI), SURVEY 8(e): one communicator per context, a side stream for the gradient all-reduce
+    ncclComm_t comm; int comm_world, comm_rank; hipStream_t comm_stream; hipEvent_t ev_ar_ready, ev_ar_done;
+    bool ar_armed, ar_issued, ar_inflight; double* adv_all;
     std::string net_err;        // set by the (void) network program on an unsupported launch; every entry point reports it as -4
 };
 
@@ -360,6 +370,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->h_f_floats = (size_t)4 * (E > 64 ? E : 64);
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
+    c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stream = nullptr; c->ev_ar_ready = c->ev_ar_done = nullptr;
+    c->ar_armed = c->ar_issued = c->ar_inflight = false; c->adv_all = nullptr;
     c->fs_grad_coef = 0.f; c->fs_G = 0;
     if (cfg->arch != MI_ARCH_IMPALA) { c->fs_colmax = nullptr; c->fs_arg = nullptr; }
     c->n_groups = 1; c->groups_live = false; c->main_stream = c->stream;
@@ -393,6 +405,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
 
 int mi_destroy(mi_ctx* c) {
     if (!c) return 0;
+    mi_comm_destroy(c);
     for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) if (c->gs[g]) hipStreamSynchronize(c->gs[g]);
     prof_harvest(c);
     hipStreamSynchronize(c->stream);
@@ -629,6 +642,19 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
     const int wlen = L.cout * 9 * L.cin;
     c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[layer], (long long)L.w_off, (long long)L.b_off, grid, wlen + L.cout, wlen};
 }
+// Gradient all-reduce of an ARMED backward pass (mi_allreduce_arm): a region of the flat gradient goes to the side stream as soon as
+// the main stream has written it for the last time.  Region A = [fc.weight .. end) (embedder.fc + heads: 84 % of the parameters, final
+// right after the first three launches of the backward pass, so their exchange hides behind the whole conv stack's backward);
+// region B = [0, fc.weight) (the 15 conv layers: final only once the per-workgroup slabs are summed, at the very end).
+static void issue_grad_allreduce(mi_ctx* c, int64_t off, int64_t n, bool last) {
+    if (!c->ar_armed || !c->comm || n <= 0) return;
+    hipEventRecord(c->ev_ar_ready, c->stream);
+    hipStreamWaitEvent(c->comm_stream, c->ev_ar_ready, 0);
+    ncclResult_t r = ncclAllReduce(c->grads + off, c->grads + off, (size_t)n, ncclFloat, ncclSum, c->comm, c->comm_stream);
+    if (r != ncclSuccess) { c->net_err = std::string("ncclAllReduce (gradients): ") + ncclGetErrorString(r); return; }
+    if (last) { hipEventRecord(c->ev_ar_done, c->comm_stream); c->ar_armed = false; c->ar_issued = true; c->ar_inflight = true; }
+}
+
 static void conv_wgrad_reduce_all(mi_ctx* c, int n) {
     if (c->slab_desc_n <= 0) return;
     int max_len = 0; double bytes = 0;
@@ -783,6 +809,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             linear_dgrad(c, dy, c->params + c->mlp[l].w_off, c->mlp_act[l], dx, n, c->mlp[l].in, c->mlp[l].out);
             dy = dx;
         }
+        issue_grad_allreduce(c, 0, c->n_params, true);
         return;
     }
     const bool fc16 = c->bf && n >= 1024;
@@ -793,6 +820,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         launch_colsum_acc(c->dfeat, n, 256, 256, c->grads + c->fc.b_off, c->col_ws, c->stream);
     } else
         linear_wgrad(c, c->dfeat, c->blk[2].P2, 1, c->grads + c->fc.w_off, c->grads + c->fc.b_off, n, 2048, c->H, c->bf);
+    issue_grad_allreduce(c, c->fc.w_off, c->n_params - c->fc.w_off, false);       // region A: fc + heads gradients are final
     float* Gout = c->GP[0];
     float* Ga = c->GP[1];
     float* Gb = c->GP[2];
@@ -898,6 +926,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         }
     }
     conv_wgrad_reduce_all(c, n);
+    issue_grad_allreduce(c, 0, c->fc.w_off, true);                                 // region B: the conv layers' gradients
 }
 
 // ------------------------------------------------------------------------------------------ predict / forward
@@ -1360,6 +1389,8 @@ int mi_optimizer_step(mi_ctx* c, float lr, float max_norm, int32_t step, float* 
     const double b1 = 0.9, b2 = 0.999;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    if (c->ar_inflight) { HIPC(hipStreamWaitEvent(c->stream, c->ev_ar_done, 0)); c->ar_inflight = false; }
+    c->ar_issued = false; c->ar_armed = false;
     launch_sumsq(c->grads, c->n_params, c->sumsq, c->sumsq + 2, c->stream);
     launch_adam(c->params, c->grads, c->adam_m, c->adam_v, c->n_params, c->sumsq, max_norm, lr, (float)b1, (float)b2, 1e-5f,
                 step_size, bc2_sqrt, c->gnorm, c->stream);
@@ -1382,6 +1413,76 @@ int mi_loss_log_read(mi_ctx* c, float* out, int32_t max_records, int32_t* n_reco
     }
     *n_records = n;
     if (reset) c->log_count = 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ collectives (RCCL over xGMI)
+int mi_comm_unique_id(void* out, size_t bytes) {
+    ARG(out && bytes >= sizeof(ncclUniqueId), "need a 128-byte buffer");
+    ncclUniqueId id;
+    NCCLC(ncclGetUniqueId(&id));
+    memcpy(out, &id, sizeof id);
+    return 0;
+}
+int mi_comm_init(mi_ctx* c, const void* id_bytes, size_t bytes, int32_t rank, int32_t world) {
+    ARG(c && id_bytes && bytes >= sizeof(ncclUniqueId), "null / short id"); ARG(world >= 1 && rank >= 0 && rank < world, "rank / world");
+    ARG(!c->comm, "communicator already initialised");
+    JOIN(c);
+    HIPC(hipSetDevice(c->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    NCCLC(ncclCommInitRank(&c->comm, world, id, rank));
+    c->comm_world = world; c->comm_rank = rank;
+    HIPC(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&c->ev_ar_ready, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&c->ev_ar_done, hipEventDisableTiming));
+    HIPC(dalloc(&c->adv_all, (size_t)3 * world + 4));
+    return 0;
+}
+int mi_comm_destroy(mi_ctx* c) {
+    if (!c || !c->comm) return 0;
+    hipStreamSynchronize(c->comm_stream); hipStreamSynchronize(c->stream);
+    ncclCommDestroy(c->comm); c->comm = nullptr;
+    hipStreamDestroy(c->comm_stream); hipEventDestroy(c->ev_ar_ready); hipEventDestroy(c->ev_ar_done);
+    hipFree(c->adv_all); c->adv_all = nullptr; c->comm_world = 1; c->comm_rank = 0;
+    c->ar_armed = c->ar_issued = c->ar_inflight = false;
+    return 0;
+}
+int mi_allreduce_arm(mi_ctx* c) {
+    ARG(c, "null"); ARG(c->comm, "no communicator: call mi_comm_init first"); ARG(!c->ar_inflight, "a gradient all-reduce is already in flight");
+    c->ar_armed = true;
+    return 0;
+}
+int mi_allreduce_grads(mi_ctx* c) {
+    ARG(c, "null"); ARG(c->comm, "no communicator: call mi_comm_init first"); JOIN(c);
+    if (c->ar_issued) return 0;              // the armed backward pass already sent both regions
+    c->ar_armed = true;
+    issue_grad_allreduce(c, 0, c->n_params, true);
+    NETCHK(c);
+    return 0;
+}
+int mi_allreduce_buffer(mi_ctx* c, int32_t which, int64_t n) {
+    ARG(c, "null"); ARG(c->comm, "no communicator: call mi_comm_init first"); JOIN(c);
+    float* p = nullptr; int64_t cap = 0;
+    switch (which) {
+        case MI_PTR_LOSS_STATS: p = c->loss_stats; cap = 32; break;
+        case MI_PTR_STATS_RING: p = c->stats_ring; cap = (int64_t)c->log_cap * 32; break;
+        case MI_PTR_GRADS: p = c->grads; cap = c->n_params; break;
+        default: return fail(-1, "mi_allreduce_buffer: unknown buffer id");
+    }
+    ARG(n >= 1 && n <= cap, "count");
+    NCCLC(ncclAllReduce(p, p, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
+    return 0;
+}
+// Storage.compute_estimates' advantage normalisation over ALL ranks' envs (common/storage.py:78-79): local {count, mean, M2} in fp64,
+// all-gather, Chan merge and the apply pass, all on the device (no host round trip)
+int mi_adv_normalize_global(mi_ctx* c) {
+    ARG(c, "null"); ARG(c->comm, "no communicator: call mi_comm_init first"); JOIN(c);
+    launch_advnorm_stats(c->adv, c->T * c->E, c->adv_stats, c->stream);
+    NCCLC(ncclAllGather(c->adv_stats, c->adv_all, 3, ncclDouble, c->comm, c->stream));
+    launch_advnorm_merge(c->adv_all, c->comm_world, c->adv_stats, c->stream);
+    launch_advnorm_apply(c->adv, c->T * c->E, c->adv_stats, c->stream);
+    HIPC(hipGetLastError());
     return 0;
 }
 

@@ -902,6 +902,23 @@ __global__ void advnorm_apply_kernel(float* adv, int n, const double* stats3) {
     const float sd = (float)sqrt(stats3[2] / (stats3[0] - 1.0));
     adv[k] = (adv[k] - mean) / (sd + 1e-8f);
 }
+// Chan et al. merge of R ranks' {count, mean, M2} triples (fp64) into stats3 -- the device side of mi355/dist.py::merge_adv_stats
+__global__ void advnorm_merge_kernel(const double* all, int R, double* stats3) {
+    if (threadIdx.x || blockIdx.x) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const double c = all[3 * r], mu = all[3 * r + 1], s = all[3 * r + 2];
+        if (c == 0.0) continue;
+        const double tot = n + c, d = mu - mean;
+        mean = mean + d * c / tot;
+        m2 = m2 + s + d * d * n * c / tot;
+        n = tot;
+    }
+    stats3[0] = n; stats3[1] = mean; stats3[2] = m2;
+}
+void launch_advnorm_merge(const double* all, int R, double* stats3, hipStream_t st) {
+    hipLaunchKernelGGL(advnorm_merge_kernel, dim3(1), dim3(64), 0, st, all, R, stats3);
+}
 void launch_advnorm_stats(const float* adv, int n, double* stats3, hipStream_t st) {
     hipLaunchKernelGGL(advnorm_stats_kernel, dim3(1), dim3(1024), 0, st, adv, n, stats3);
 }

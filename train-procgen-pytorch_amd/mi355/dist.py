@@ -106,6 +106,18 @@ class Collective:
         self.rank = td.get_rank(group) if self.active else 0
         self.world = td.get_world_size(group) if self.active else 1
 
+    def attach_native(self, engine):
+        """RCCL inside the library (include/mi355ppo.h mi_comm_*): with the "nccl" backend the engine gets its own communicator
+        (rank 0's 128-byte id reaches the others through this process group) and gradient / statistics collectives run behind the
+        C ABI, the gradient exchange overlapped with the backward pass.  gloo (CPU tests, --rehearse-on-one-gpu) keeps the
+        torch.distributed calls on aliased device buffers below."""
+        if not self.active or self.td.get_backend(self.group) != "nccl":
+            return False
+        box = [engine.comm_unique_id() if self.rank == 0 else None]
+        self.td.broadcast_object_list(box, src=0, group=self.group)
+        engine.comm_init(box[0], self.rank, self.world)
+        return True
+
     def allreduce_sum_(self, tensor):
         if self.active:
             self.td.all_reduce(tensor, op=self.td.ReduceOp.SUM, group=self.group)
