@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--param_name", default="hard-500")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="rollout steps (of all E envs) the CPU baseline leg runs")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="rollout steps (of all E envs) the CPU baseline leg runs")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
                     help="activation storage: fp32 = parity mode; bf16 = BASELINE config 3 (bf16 storage + bf16 MFMA fwd/dgrad)")
@@ -338,7 +338,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if args.precision == "bf16" else "f32"), "data": "synthetic" + (" -- REHEARSAL: every rank on GPU 0, gloo; not a result" if args.rehearse_on_one_gpu else ""),
                "config": {"workload": f"PPO iteration, {args.param_name}: IMPALA-CNN, T={T}, E={E} envs per GPU, "
-                                      f"{hp['epoch']} epochs x {hp['n_minibatch']} minibatches of {agent.mini_batch_size} (global), "
+                                      f"{hp['epoch']} epochs x {agent.n_minibatch} minibatches of {agent.mini_batch_size} (global), "
                                       f"A={A} (--no-reduce_duplicate_actions; the reference default merges them to 9), "
                                       + (f"every policy step uploads its E frames from pinned host memory (pipelined over {G} env groups)" if host_frames is not None
                                          else "DIAGNOSTIC --no-h2d: frames resident in HBM, no per-step upload"),
