@@ -220,6 +220,9 @@ int mi_selftest_mfma(mi_ctx* ctx, float* max_err);
  * 1 res1.conv1 out, 2 res1 out, 3 res2.conv1 out, 4 block out, 5 max-pool arg-max (window position ky*3+kx); which = 100: features.
  * Lets a parity test run the oracle's backward pass on the ENGINE's forward tensors (teacher forcing, tests/test_gpu_bf16.py). */
 int mi_debug_read(mi_ctx* ctx, int32_t which, int32_t n, float* out);
+/* bit 0 set: rollout-sized bf16 inference passes use the separate block-2 / block-3 kernels instead of the fused launch
+ * (rollout_bf16.hip) -- the A side of the bit-equality test of the two paths */
+int mi_debug_flags(mi_ctx* ctx, int32_t flags);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 """Where a pipelined rollout step goes: host time inside rollout_submit (copy enqueue + launches), inside rollout_wait (spin
 until the group's actions are on the host) and in the Python between them.  python scratch/rollout_pipe.py [G] [E]"""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "train-procgen-pytorch_amd")):
     sys.path.insert(0, p)

@@ -345,6 +345,34 @@ def test_feature_sparsity_gradient_bf16_against_bf16_oracle():
     eng.close()
 
 
+@pytest.mark.parametrize("n", [1, 7, 64, 256])
+def test_fused_rollout_tail_equals_the_four_launches(n):
+    """Rollout-sized inference passes (n <= 256, bf16) run IMPALA blocks 2 + 3 -- conv+pool, res pair, conv+pool, res pair -- as one
+    launch with one workgroup per image (rollout_bf16.hip).  Same banks, same K order per output pixel, same rounding points, same
+    first-maximum pooling: features, log-probs and values are BIT-identical to the four-launch path (mi_debug_flags bit 0), which
+    in turn is what the update's training-mode forward runs.  Frames include flat patches (pooling ties) and saturated rows."""
+    from mi355 import layout
+    from mi355.engine import Engine
+    z = load_npz("g3_impala_forward.npz")
+    flat = layout.flatten(layout.impala_param_shapes(15), npz_params(z))
+    rng = np.random.default_rng(n)
+    frames = rng.integers(0, 256, size=(n, 64, 64, 3), dtype=np.uint8)
+    frames[0, 8:40, 4:60] = 128
+    if n > 2:
+        frames[2] = 255; frames[1, :, :32] = 0
+    eng = Engine("impala", 2, 8, 15, 256, precision="bf16")
+    eng.set_params(flat * np.float32(1.7))                 # larger activations: more pooling / ReLU decisions in play
+    fused = eng.forward(frames, want_feat=True)
+    eng.debug_flags(1)
+    plain = eng.forward(frames, want_feat=True)
+    eng.debug_flags(0)
+    again = eng.forward(frames, want_feat=True)
+    eng.close()
+    assert np.abs(plain[2]).max() > 1e-2
+    for a, b, c in zip(fused, plain, again):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
 def test_fc_bf16_matrix_core_path_matches_small_batch_path():
     """Minibatches of >= 1024 samples route embedder.fc through the bf16-MFMA NT/TN kernels (fc_bf16.hip); smaller
     ones through the fp32-MFMA GEMM on the same bf16-stored activations.  One 1024-sample minibatch must equal the

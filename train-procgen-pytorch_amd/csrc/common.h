@@ -220,6 +220,8 @@ void launch_fc_fwd_bf16(const void* x_bf16, const unsigned short* wp, const floa
 void launch_fc_dgrad_bf16(const float* dy, const unsigned short* wt, const void* mask_bf16, void* dx_bf16, int n, hipStream_t st);
 void launch_fc_tn(const float* A, const unsigned short* B, float* gW, float* ws, size_t ws_floats, int M, int N, int K, hipStream_t st);
 
+// blocks 2 + 3 of a rollout-sized batch (n <= 256) in one launch (rollout_bf16.hip): bank / bias = their ten convs in network order
+void launch_rollout_tail_bf16(const void* x, void* y, int n, const unsigned short* const* bank, const float* const* bias, hipStream_t st);
 // fused residual block forward, bf16 mode (resblock_bf16.hip); s = ConvShape of the block's convs
 bool launch_conv_pool_fwd_bf16(ConvShape s, const ConvArgs& a, void* p_out, uint8_t* p_arg, hipStream_t st);
 void launch_resblock_bf16(ConvShape s, const void* x, const float* b1, const float* b2, void* a_out, void* y_out, int n,

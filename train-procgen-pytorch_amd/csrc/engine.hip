@@ -16,9 +16,19 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 static std::vector<uint16_t> host_to_bf16(const float* x, size_t n);
 static thread_local std::string g_err;
+// A worker thread of the pipelined rollout issues one env group's pass on that group's stream with that group's slice of the split-K
+// workspace: the network program reads both through these thread-local overrides (null on every other thread: the context's own).
+static thread_local hipStream_t tl_stream = nullptr;
+static thread_local float* tl_ws = nullptr;
+static thread_local size_t tl_ws_floats = 0;
+#define CUR(c) (tl_stream ? tl_stream : (c)->stream)
 const char* mi_last_error(void) { return g_err.c_str(); }
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -78,6 +88,13 @@ struct Profiler {
 
 struct mi_ctx;
 static void prof_harvest(mi_ctx* c);
+// one step of one env group, as the submitting thread hands it to the group's worker
+struct GroupJob { int t; const void* frames; size_t bytes; bool have_rd, last; const float* u; unsigned long long seed; unsigned ticket; };
+struct GroupWorker {
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    std::atomic<unsigned> posted{0}, done{0}; std::atomic<bool> sleeping{false}, quit{false};
+    GroupJob job{}; int rc = 0; std::string err;
+};
 
 struct mi_ctx {
     Profiler prof;
@@ -139,6 +156,8 @@ struct mi_ctx {
     static constexpr int MAX_GROUPS = 4;
     int n_groups; hipStream_t main_stream, gs[MAX_GROUPS]; hipEvent_t ev_fork[MAX_GROUPS], ev_join[MAX_GROUPS];
     bool g_forked[MAX_GROUPS], g_busy[MAX_GROUPS], g_last[MAX_GROUPS], g_dirty[MAX_GROUPS]; unsigned g_ticket[MAX_GROUPS]; bool groups_live;
+    struct GroupWorker* gw[MAX_GROUPS];      // one host thread per group issues that group's copies + launches (a step is ~9 API calls = ~30 us of host time)
+    bool rollout_tail;          // bf16 inference passes of <= 256 samples run blocks 2 + 3 as one launch (mi_debug_flags bit 0 clears it: A/B tests)
     float *fs_colmax, fs_grad_coef; int *fs_arg, fs_G;      // feature-sparsity gradient (fs_coef != 0): column maxima / first arg-max rows of the minibatch
     // data-parallel collectives (RCCL over xGMI), SURVEY 8(e): one communicator per context, a side stream for the gradient all-reduce
     ncclComm_t comm; int comm_world, comm_rank; hipStream_t comm_stream; hipEvent_t ev_ar_ready, ev_ar_done;
@@ -372,10 +391,10 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
     c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stream = nullptr; c->ev_ar_ready = c->ev_ar_done = nullptr;
     c->ar_armed = c->ar_issued = c->ar_inflight = false; c->adv_all = nullptr;
-    c->fs_grad_coef = 0.f; c->fs_G = 0;
+    c->fs_grad_coef = 0.f; c->fs_G = 0; c->rollout_tail = true;
     if (cfg->arch != MI_ARCH_IMPALA) { c->fs_colmax = nullptr; c->fs_arg = nullptr; }
     c->n_groups = 1; c->groups_live = false; c->main_stream = c->stream;
-    for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) { c->gs[g] = nullptr; c->ev_fork[g] = c->ev_join[g] = nullptr; c->g_forked[g] = c->g_busy[g] = c->g_last[g] = c->g_dirty[g] = false; c->g_ticket[g] = 0; }
+    for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) { c->gw[g] = nullptr; c->gs[g] = nullptr; c->ev_fork[g] = c->ev_join[g] = nullptr; c->g_forked[g] = c->g_busy[g] = c->g_last[g] = c->g_dirty[g] = false; c->g_ticket[g] = 0; }
     c->multirank = 0; c->pending_n = -1; c->sal_dc = nullptr; c->sal_dx = nullptr; c->sal_src = nullptr;
     c->fc_wp = c->fc_wt = nullptr; c->fc_packed_valid = false;
     if (c->bf) { HIPC(dalloc(&c->fc_wp, (size_t)256 * 2048)); HIPC(dalloc(&c->fc_wt, (size_t)256 * 2048)); }
@@ -406,6 +425,12 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
 int mi_destroy(mi_ctx* c) {
     if (!c) return 0;
     mi_comm_destroy(c);
+    for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g)
+        if (c->gw[g]) {
+            GroupWorker* w = c->gw[g];
+            w->quit.store(true); { std::lock_guard<std::mutex> lk(w->mu); } w->cv.notify_one();
+            w->th.join(); delete w; c->gw[g] = nullptr;
+        }
     for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) if (c->gs[g]) hipStreamSynchronize(c->gs[g]);
     prof_harvest(c);
     hipStreamSynchronize(c->stream);
@@ -560,7 +585,7 @@ struct ProfScope {
     mi_ctx* c; ProfPending p; bool live;
     // bytes / flops: ALGORITHMIC figures of this launch (layer-boundary model)
     ProfScope(mi_ctx* c_, int cls, long long units, double bytes, double flops)
-        : c(c_), live(c_->prof.on && (c_->prof.phase == 1 ? c_->prof.sample_now : c_->prof.all_phases)) {
+        : c(c_), live(!tl_stream && c_->prof.on && (c_->prof.phase == 1 ? c_->prof.sample_now : c_->prof.all_phases)) {
         if (!live) return;
         p.a = prof_event(c); p.b = prof_event(c); p.cls = cls; p.phase = c->prof.phase; p.units = units; p.bytes = bytes; p.flops = flops;
         hipEventRecord(p.a, c->stream);
@@ -610,7 +635,7 @@ static void conv_fwd(mi_ctx* c, const ConvLayer& L, const void* in, const InputS
     a.lut16 = c->bf ? c->lut16 : nullptr;
     const double px = (double)n * L.hw * L.hw, es = c->es;
     ProfScope ps(c, PC_CONV_FWD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : es * L.cin) + es * L.cout * (res ? 2 : 1)), px * 18.0 * L.cin * L.cout);
-    launch_conv_fwd(L.shape, a, c->stream);
+    launch_conv_fwd(L.shape, a, CUR(c));
 }
 static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const float* mask, const float* res, float* din, int n, const uint8_t* pool_arg = nullptr) {
     ConvArgs a{};
@@ -621,7 +646,7 @@ static void conv_dgrad(mi_ctx* c, const ConvLayer& L, const float* dout, const f
     const double px = (double)n * L.hw * L.hw;
     const double pool_b = pool_arg ? c->es * (px / 4 * L.cout + 2.0 * px * L.cout) : 0.0;      // POOLIN: the max-pool backward (p + 2X of SURVEY 8(d)) rides along
     ProfScope ps(c, PC_CONV_DGRAD + (int)L.shape, n, px * c->es * (L.cout + L.cin * (1 + (mask ? 1 : 0) + (res ? 1 : 0))) + pool_b, px * 18.0 * L.cin * L.cout);
-    launch_conv_dgrad(L.shape, a, c->stream);
+    launch_conv_dgrad(L.shape, a, CUR(c));
 }
 static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const InputSrc* src, int relu_in, const float* dout, int n, const uint8_t* pool_arg = nullptr) {
     WgradArgs a{};
@@ -637,7 +662,7 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
     { // SURVEY 8(d) layer-boundary bytes; block1.conv from the pooled gradient also carries the max-pool backward (p + 2X)
       const double pool_b = (pool_arg && L.cin == 3) ? c->es * (px / 4 * L.cout + 2.0 * px * L.cout) : 0.0;
       ProfScope ps(c, PC_CONV_WGRAD + (int)L.shape, n, px * ((L.cin == 3 ? 3.0 : c->es * L.cin) + c->es * L.cout) + pool_b, px * 18.0 * L.cin * L.cout);
-      launch_conv_wgrad(L.shape, a, c->stream); }
+      launch_conv_wgrad(L.shape, a, CUR(c)); }
     // the slabs of all layers are summed by ONE launch at the end of net_backward (conv_wgrad_reduce_all)
     const int wlen = L.cout * 9 * L.cin;
     c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[layer], (long long)L.w_off, (long long)L.b_off, grid, wlen + L.cout, wlen};
@@ -648,7 +673,7 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
 // region B = [0, fc.weight) (the 15 conv layers: final only once the per-workgroup slabs are summed, at the very end).
 static void issue_grad_allreduce(mi_ctx* c, int64_t off, int64_t n, bool last) {
     if (!c->ar_armed || !c->comm || n <= 0) return;
-    hipEventRecord(c->ev_ar_ready, c->stream);
+    hipEventRecord(c->ev_ar_ready, CUR(c));
     hipStreamWaitEvent(c->comm_stream, c->ev_ar_ready, 0);
     ncclResult_t r = ncclAllReduce(c->grads + off, c->grads + off, (size_t)n, ncclFloat, ncclSum, c->comm, c->comm_stream);
     if (r != ncclSuccess) { c->net_err = std::string("ncclAllReduce (gradients): ") + ncclGetErrorString(r); return; }
@@ -661,44 +686,44 @@ static void conv_wgrad_reduce_all(mi_ctx* c, int n) {
     for (int k = 0; k < c->slab_desc_n; ++k) { max_len = std::max(max_len, c->h_slab_desc[k].slab_len); bytes += 4.0 * c->h_slab_desc[k].nslab * c->h_slab_desc[k].slab_len; }
     // the descriptor table only depends on the batch size: re-uploaded when it changes (pageable source copied at call time)
     if (c->slab_desc_cached_n != n) {
-        hipMemcpyAsync(c->d_slab_desc, c->h_slab_desc, sizeof(SlabDesc) * c->slab_desc_n, hipMemcpyHostToDevice, c->stream);
+        hipMemcpyAsync(c->d_slab_desc, c->h_slab_desc, sizeof(SlabDesc) * c->slab_desc_n, hipMemcpyHostToDevice, CUR(c));
         c->slab_desc_cached_n = n;
     }
     { ProfScope ps(c, PC_SLAB_REDUCE, n, bytes, 0.0);
-      launch_reduce_all_slabs(c->slabs, c->grads, c->d_slab_desc, c->slab_desc_n, max_len, c->stream); }
+      launch_reduce_all_slabs(c->slabs, c->grads, c->d_slab_desc, c->slab_desc_n, max_len, CUR(c)); }
     c->slab_desc_n = 0;
 }
 
 static void linear_fwd(mi_ctx* c, const float* X, int relu_x, const float* W, const float* b, float* Y, int n, int in, int out, int relu_out, int x_bf16 = 0) {
     GemmArgs g{};
-    g.ws = c->gemm_ws; g.ws_floats = c->gemm_ws_floats;
+    g.ws = tl_ws ? tl_ws : c->gemm_ws; g.ws_floats = tl_ws ? tl_ws_floats : c->gemm_ws_floats;
     g.a_bf16 = x_bf16;
     g.A = X; g.B = W; g.C = Y; g.M = n; g.N = out; g.K = in;
     g.sam = in; g.sak = 1; g.sbk = 1; g.sbn = in; g.ldc = out;
     g.bias = b; g.relu_a = relu_x; g.relu_out = relu_out;
     ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * in + (double)in * out + (double)n * out), 2.0 * n * in * out);
-    launch_gemm(g, c->stream);
+    launch_gemm(g, CUR(c));
 }
 // dX = dY W  (* mask > 0)
 static void linear_dgrad(mi_ctx* c, const float* dY, const float* W, const float* mask, float* dX, int n, int in, int out, int x_bf16 = 0) {
     GemmArgs g{};
-    g.ws = c->gemm_ws; g.ws_floats = c->gemm_ws_floats;
+    g.ws = tl_ws ? tl_ws : c->gemm_ws; g.ws_floats = tl_ws ? tl_ws_floats : c->gemm_ws_floats;
     g.mask_bf16 = x_bf16; g.c_bf16 = x_bf16;          // mask source and dX are activation-typed
     g.A = dY; g.B = W; g.C = dX; g.M = n; g.N = in; g.K = out;
     g.sam = out; g.sak = 1; g.sbk = in; g.sbn = 1; g.ldc = in; g.mask = mask;
     ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * out + (double)in * out + (double)n * in * (mask ? 2 : 1)), 2.0 * n * in * out);
-    launch_gemm(g, c->stream);
+    launch_gemm(g, CUR(c));
 }
 // gW += dY^T relu?(X) ; gb += colsum(dY)
 static void linear_wgrad(mi_ctx* c, const float* dY, const float* X, int relu_x, float* gW, float* gb, int n, int in, int out, int x_bf16 = 0) {
     GemmArgs g{};
-    g.ws = c->gemm_ws; g.ws_floats = c->gemm_ws_floats;
+    g.ws = tl_ws ? tl_ws : c->gemm_ws; g.ws_floats = tl_ws ? tl_ws_floats : c->gemm_ws_floats;
     g.b_bf16 = x_bf16;
     g.A = dY; g.B = X; g.C = gW; g.M = out; g.N = in; g.K = n;
     g.sam = 1; g.sak = out; g.sbk = in; g.sbn = 1; g.ldc = in; g.relu_b = relu_x; g.accumulate = 1;
     ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * out + (double)n * in + (double)in * out), 2.0 * n * in * out);
-    launch_gemm(g, c->stream);
-    launch_colsum_acc(dY, n, out, out, gb, c->col_ws, c->stream);
+    launch_gemm(g, CUR(c));
+    launch_colsum_acc(dY, n, out, out, gb, c->col_ws, CUR(c));
 }
 
 static void net_heads(mi_ctx* c, int n, int soff = 0) {
@@ -708,17 +733,17 @@ static void net_heads(mi_ctx* c, int n, int soff = 0) {
 static void net_gru(mi_ctx* c, int n, int soff = 0) {
     const int H = c->H;
     const size_t o = (size_t)soff * H;
-    launch_mask_rows(c->h_state + o, c->d_done + soff, c->h_masked + o, n, H, c->stream);
+    launch_mask_rows(c->h_state + o, c->d_done + soff, c->h_masked + o, n, H, CUR(c));
     linear_fwd(c, c->feat + o, 0, c->gru_wih, c->gru_bih, c->gru_gi + 3 * o, n, H, 3 * H, 0);
     linear_fwd(c, c->h_masked + o, 0, c->gru_whh, c->gru_bhh, c->gru_gh + 3 * o, n, H, 3 * H, 0);
-    launch_gru_gates(c->gru_gi + 3 * o, c->gru_gh + 3 * o, c->h_masked + o, c->h_state + o, c->feat + o, n, H, c->stream);
+    launch_gru_gates(c->gru_gi + 3 * o, c->gru_gh + 3 * o, c->h_masked + o, c->h_state + o, c->feat + o, n, H, CUR(c));
 }
 
 static void fc_refresh(mi_ctx* c) {
     if (c->bf && !c->fc_packed_valid) {
-        launch_fc_pack(c->params + c->fc.w_off, c->fc_wp, c->fc_wt, 256, 2048, c->stream);
-        launch_pack_banks(c->params, c->banks, c->d_bank_desc, c->n_banks, c->stream);
-        if (c->c1_bank && !c->convs.empty()) launch_pack_conv1_bank(c->params + c->convs[0].w_off, c->c1_bank, c->stream);
+        launch_fc_pack(c->params + c->fc.w_off, c->fc_wp, c->fc_wt, 256, 2048, CUR(c));
+        launch_pack_banks(c->params, c->banks, c->d_bank_desc, c->n_banks, CUR(c));
+        if (c->c1_bank && !c->convs.empty()) launch_pack_conv1_bank(c->params + c->convs[0].w_off, c->c1_bank, CUR(c));
         c->fc_packed_valid = true;
     }
 }
@@ -730,40 +755,56 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
     float* const feat = c->feat + (size_t)soff * c->H;
     if (c->cfg.arch == MI_ARCH_IMPALA) {
         const float* prev = nullptr;
-        for (int b = 0; b < 3; ++b) {
+        auto view = [&](int b) {       // block b's buffers from row soff on (element size: c->es bytes; arg-max: 1 byte)
             Block k = c->blk[b];
-            if (soff) {         // shifted view of the block's buffers (element size: c->es bytes; arg-max: 1 byte)
+            if (soff) {
                 const size_t pe = (size_t)(k.hin / 2) * (k.hin / 2) * k.cout, po = (size_t)soff * pe * (size_t)c->es;
                 auto sh = [&](float* q, size_t bytes) { return q ? (float*)((char*)q + bytes) : q; };
                 k.C = sh(k.C, po * 4); k.P0 = sh(k.P0, po); k.A1 = sh(k.A1, po); k.P1 = sh(k.P1, po); k.A2 = sh(k.A2, po); k.P2 = sh(k.P2, po);
                 k.PI += (size_t)soff * pe;
             }
+            return k;
+        };
+        // rollout-sized inference batches (bf16): blocks 2 and 3 in ONE launch, one workgroup per image (rollout_bf16.hip)
+        const bool fused_tail = c->bf && !train && n <= 256 && c->rollout_tail;
+        for (int b = 0; b < 3; ++b) {
+            Block k = view(b);
             const ConvLayer* L = &c->convs[b * 5];
+            if (fused_tail && b == 1) {
+                const unsigned short* bk[10]; const float* bb[10];
+                for (int q = 0; q < 10; ++q) { bk[q] = c->banks + c->convs[5 + q].bank_f; bb[q] = c->params + c->convs[5 + q].b_off; }
+                const Block k3 = view(2);
+                { const double px2 = (double)n * 32 * 32, px3 = (double)n * 16 * 16;
+                  ProfScope ps(c, PC_RESBLOCK + (int)CS_32_32_16, n, 2.0 * (px2 * 16 + px3 / 4 * 32), px2 * 18.0 * 16 * 32 + 5.0 * px3 * 18.0 * 32 * 32 + 4.0 * (px3 / 4) * 18.0 * 32 * 32);
+                  launch_rollout_tail_bf16(prev, k3.P2, n, bk, bb, CUR(c)); }
+                prev = k3.P2;
+                break;
+            }
             if (b == 0 && c->bf) {           // block1.conv + max pool fused: the 64x64x16 conv output never reaches HBM
                 ConvArgs a{};
                 a.in = src.base; a.idx = src.idx; a.in_base = src.first; a.w = c->params + L[0].w_off; a.bias = c->params + L[0].b_off;
                 a.n = n; a.bf16 = 1; a.lut16 = c->lut16; a.wbank = c->c1_bank;
                 const double px = (double)n * 64 * 64;
                 ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, px * 3.0 + 2.0 * (2.0 * px * 16 + px / 4 * 16), px * 18.0 * 3 * 16);      // conv I + X, pool X + p
-                launch_conv1_pool_fwd_bf16(a, c->lut16, k.P0, k.PI, c->stream);
+                launch_conv1_pool_fwd_bf16(a, c->lut16, k.P0, k.PI, CUR(c));
             } else if (c->bf && L[0].bank_f >= 0) {       // block2.conv / block3.conv + max pool fused as well (convpool_bf16.hip)
                 ConvArgs a{};
                 a.in = prev; a.bias = c->params + L[0].b_off; a.n = n; a.bf16 = 1; a.wbank = c->banks + L[0].bank_f;
                 const double px = (double)n * L[0].hw * L[0].hw;
                 ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, 2.0 * (px * L[0].cin + 2.0 * px * L[0].cout + px / 4 * L[0].cout), px * 18.0 * L[0].cin * L[0].cout);      // 8(d): I + 2X + p
-                if (!launch_conv_pool_fwd_bf16(L[0].shape, a, k.P0, k.PI, c->stream)) { c->net_err = "no fused conv+pool kernel for this conv shape"; return; }
+                if (!launch_conv_pool_fwd_bf16(L[0].shape, a, k.P0, k.PI, CUR(c))) { c->net_err = "no fused conv+pool kernel for this conv shape"; return; }
             } else {
             if (b == 0) conv_fwd(c, L[0], nullptr, &src, 0, nullptr, k.C, n);
             else conv_fwd(c, L[0], prev, nullptr, 0, nullptr, k.C, n);
             { ProfScope ps(c, PC_POOL_FWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
-              if (c->bf) launch_maxpool_fwd_bf16(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); else launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, c->stream); }
+              if (c->bf) launch_maxpool_fwd_bf16(k.C, k.P0, k.PI, n, k.hin, k.cout, CUR(c)); else launch_maxpool_fwd(k.C, k.P0, k.PI, n, k.hin, k.cout, CUR(c)); }
             }
             if (c->bf) {                     // res1 + res2 in ONE launch; intermediates reach HBM only when a backward pass follows
                 const double px = (double)n * L[1].hw * L[1].hw, ch = L[1].cout;
                 const float* bb[4] = {c->params + L[1].b_off, c->params + L[2].b_off, c->params + L[3].b_off, c->params + L[4].b_off};
                 const unsigned short* bk[4] = {c->banks + L[1].bank_f, c->banks + L[2].bank_f, c->banks + L[3].bank_f, c->banks + L[4].bank_f};
                 ProfScope ps(c, PC_RESBLOCK + (int)L[1].shape, n, px * ch * 2.0 * 10, 4.0 * px * 18.0 * ch * ch);      // 8(d): 2 blocks x (2 convs x 2p + skip p) = 10p (the kernel itself moves 5p)
-                launch_resblock_pair_bf16(L[1].shape, k.P0, bb, train ? k.A1 : nullptr, train ? k.P1 : nullptr, train ? k.A2 : nullptr, k.P2, n, bk, c->stream);
+                launch_resblock_pair_bf16(L[1].shape, k.P0, bb, train ? k.A1 : nullptr, train ? k.P1 : nullptr, train ? k.A2 : nullptr, k.P2, n, bk, CUR(c));
             } else {
                 conv_fwd(c, L[1], k.P0, nullptr, 1, nullptr, k.A1, n);
                 conv_fwd(c, L[2], k.A1, nullptr, 1, k.P0, k.P1, n);
@@ -775,13 +816,13 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
         const float* last_p2 = prev;
         if (c->bf) {                            // bf16 matrix cores on the packed [256][2048] weight image (fc_bf16.hip)
             ProfScope ps(c, PC_GEMM, n, 2.0 * n * 2048 + 2.0 * 2048 * 256 + 4.0 * n * 256, 2.0 * n * 2048 * 256);
-            if (n >= 1024) launch_fc_fwd_bf16(last_p2, c->fc_wp, c->params + c->fc.b_off, feat, n, c->stream);
-            else launch_fc_fwd_small_bf16(last_p2, c->fc_wp, c->params + c->fc.b_off, feat, n, c->stream);   // rollout-sized: latency-bound
+            if (n >= 1024) launch_fc_fwd_bf16(last_p2, c->fc_wp, c->params + c->fc.b_off, feat, n, CUR(c));
+            else launch_fc_fwd_small_bf16(last_p2, c->fc_wp, c->params + c->fc.b_off, feat, n, CUR(c));   // rollout-sized: latency-bound
         } else
             linear_fwd(c, last_p2, 1, c->params + c->fc.w_off, c->params + c->fc.b_off, feat, n, 2048, c->H, 1, c->bf);
     } else {
         float* x0 = c->mlp_act[0] + (size_t)soff * c->cfg.obs_dim;
-        launch_gather_rows((const float*)src.base, src.idx, src.first, x0, n, c->cfg.obs_dim, c->stream);
+        launch_gather_rows((const float*)src.base, src.idx, src.first, x0, n, c->cfg.obs_dim, CUR(c));
         const size_t L = c->mlp.size();
         const float* x = x0;
         for (size_t l = 0; l < L; ++l) {
@@ -816,8 +857,8 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     if (fc16) {
         fc_refresh(c);
         { ProfScope ps(c, PC_GEMM, n, 2.0 * n * 2048 + 4.0 * n * 256 + 4.0 * 2048 * 256, 2.0 * n * 2048 * 256);
-          launch_fc_tn(c->dfeat, (const unsigned short*)c->blk[2].P2, c->grads + c->fc.w_off, c->gemm_ws, (size_t)8 << 20, 256, 2048, n, c->stream); }
-        launch_colsum_acc(c->dfeat, n, 256, 256, c->grads + c->fc.b_off, c->col_ws, c->stream);
+          launch_fc_tn(c->dfeat, (const unsigned short*)c->blk[2].P2, c->grads + c->fc.w_off, c->gemm_ws, (size_t)8 << 20, 256, 2048, n, CUR(c)); }
+        launch_colsum_acc(c->dfeat, n, 256, 256, c->grads + c->fc.b_off, c->col_ws, CUR(c));
     } else
         linear_wgrad(c, c->dfeat, c->blk[2].P2, 1, c->grads + c->fc.w_off, c->grads + c->fc.b_off, n, 2048, c->H, c->bf);
     issue_grad_allreduce(c, c->fc.w_off, c->n_params - c->fc.w_off, false);       // region A: fc + heads gradients are final
@@ -826,11 +867,11 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     float* Gb = c->GP[2];
     if (fc16) {
         ProfScope ps(c, PC_GEMM, n, 4.0 * n * 256 + 2.0 * 2048 * 256 + 2.0 * 2.0 * n * 2048, 2.0 * n * 2048 * 256);
-        launch_fc_dgrad_bf16(c->dfeat, c->fc_wt, c->blk[2].P2, Gout, n, c->stream);
+        launch_fc_dgrad_bf16(c->dfeat, c->fc_wt, c->blk[2].P2, Gout, n, CUR(c));
     } else
         linear_dgrad(c, c->dfeat, c->params + c->fc.w_off, c->blk[2].P2, Gout, n, 2048, c->H, c->bf);
     if (c->fs_grad_coef != 0.f)      // + fs_coef * d(feature sparsity) / d(block3 output): one element per column (launch_fs_grad, misc.hip)
-        launch_fs_grad(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_G, Gout, c->fs_grad_coef, c->fs_colmax, c->fs_arg, c->stream);
+        launch_fs_grad(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_G, Gout, c->fs_grad_coef, c->fs_colmax, c->fs_arg, CUR(c));
     for (int b = 2; b >= 0; --b) {
         Block& k = c->blk[b];
         const ConvLayer* L = &c->convs[b * 5];
@@ -844,7 +885,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
                 const int i1 = (int)(&l1 - c->convs.data()), i2 = (int)(&l2 - c->convs.data());
                 { ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 7, 4.0 * px * 18.0 * ch * ch);      // 8(d): 2 convs x 3p + skip-gradient p = 7p (the kernel itself moves 4p)
                   launch_resblock_bwd_full32_bf16(l1.shape, dy, a_fwd, x_fwd, dx, nullptr, n, c->banks + l2.bank_d, c->banks + l1.bank_d,
-                                                  c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], c->stream); }
+                                                  c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], CUR(c)); }
                 const int wlen = l1.cout * 9 * l1.cin;
                 c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[i2], (long long)l2.w_off, (long long)l2.b_off, grid, wlen + l2.cout, wlen};
                 c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[i1], (long long)l1.w_off, (long long)l1.b_off, grid, wlen + l1.cout, wlen};
@@ -857,7 +898,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             const double px = (double)n * L[1].hw * L[1].hw, ch = L[1].cout;
             auto rb_bwd = [&](const ConvLayer& l1, const ConvLayer& l2, const float* dy, const float* a_fwd, const float* x_fwd, float* da, float* dx) {
                 ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 5, 2.0 * px * 18.0 * ch * ch);
-                launch_resblock_bwd_bf16(l1.shape, dy, a_fwd, x_fwd, da, dx, n, c->banks + l2.bank_d, c->banks + l1.bank_d, c->stream);
+                launch_resblock_bwd_bf16(l1.shape, dy, a_fwd, x_fwd, da, dx, n, c->banks + l2.bank_d, c->banks + l1.bank_d, CUR(c));
             };
             if (L[1].shape == CS_16_16_32) {
                 // 16 channels @32x32: data gradients AND both weight gradients in one launch (resblock_bwd_full_bf16_kernel);
@@ -867,7 +908,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
                     const int i1 = (int)(&l1 - c->convs.data()), i2 = (int)(&l2 - c->convs.data());
                     { ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 7, 4.0 * px * 18.0 * ch * ch);      // 8(d): 2 convs x 3p + skip-gradient p = 7p (the kernel itself moves 4p)
                       launch_resblock_bwd_full_bf16(dy, a_fwd, x_fwd, dx, nullptr, n, c->banks + l2.bank_d, c->banks + l1.bank_d,
-                                                    c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], c->stream); }
+                                                    c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], CUR(c)); }
                     const int wlen = l1.cout * 9 * l1.cin;
                     c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[i2], (long long)l2.w_off, (long long)l2.b_off, grid, wlen + l2.cout, wlen};
                     c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[i1], (long long)l1.w_off, (long long)l1.b_off, grid, wlen + l1.cout, wlen};
@@ -907,7 +948,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
                 a.wg_in = c->blk[b - 1].P2; a.wg_partial = c->slabs + c->slab_off[layer];
                 const double px = (double)n * L[0].hw * L[0].hw;
                 { ProfScope ps(c, PC_CONV_DGRAD + (int)L[0].shape, n, 2.0 * (px / 4 * L[0].cout + 3.0 * px * L[0].cout + 2.0 * px * L[0].cin), 2.0 * px * 18.0 * L[0].cin * L[0].cout);      // 8(d): pool bwd p + 2X, conv bwd X + 2I
-                  launch_conv_dgrad(L[0].shape, a, c->stream); }
+                  launch_conv_dgrad(L[0].shape, a, CUR(c)); }
                 const int wlen = L[0].cout * 9 * L[0].cin;
                 c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[layer], (long long)L[0].w_off, (long long)L[0].b_off, fgrid, wlen + L[0].cout, wlen};
             } else {
@@ -918,7 +959,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             continue;
         }
         { ProfScope ps(c, PC_POOL_BWD, n, (double)n * k.hin * k.hin * k.cout * (c->es * 1.25 + 0.25), 0.0);
-          if (c->bf) launch_maxpool_bwd_bf16(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); else launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, c->stream); }
+          if (c->bf) launch_maxpool_bwd_bf16(Gout, k.PI, c->GC, n, k.hin, k.cout, CUR(c)); else launch_maxpool_bwd(Gout, k.PI, c->GC, n, k.hin, k.cout, CUR(c)); }
         if (b == 0) { c->sal_src = c->GC; conv_wgrad(c, L[0], nullptr, &src, 0, c->GC, n); }
         else {
             conv_wgrad(c, L[0], c->blk[b - 1].P2, nullptr, 0, c->GC, n);
@@ -1005,9 +1046,14 @@ int mi_rollout_step(mi_ctx* c, int32_t t, const float* rew_prev, const float* do
 // are independent: group g's upload (PCIe, ~37 us for 128 frames) and forward run on stream gs[g] while the host waits for / steps
 // another group.  Per group: its own stream, rows [e0, e0 + E/G) of the activation buffers, its slice of the pinned hand-off
 // buffers, its own completion ticket.  Numbers are those of mi_rollout_step (same kernels, same Philox counters t*E + e).
+static void worker_drain(GroupWorker* w) {       // until the worker has issued everything that was posted to it
+    if (!w) return;
+    while (w->done.load(std::memory_order_acquire) != w->posted.load(std::memory_order_acquire)) __builtin_ia32_pause();
+}
 static int join_groups(mi_ctx* c) {
     for (int g = 0; g < c->n_groups; ++g) {
         if (!c->gs[g]) continue;
+        worker_drain(c->gw[g]);
         if (c->g_dirty[g]) {
             HIPC(hipEventRecord(c->ev_join[g], c->gs[g]));
             HIPC(hipStreamWaitEvent(c->main_stream, c->ev_join[g], 0));
@@ -1017,6 +1063,52 @@ static int join_groups(mi_ctx* c) {
     }
     c->groups_live = false;
     return 0;
+}
+
+// the device half of a group step, on the group's worker thread (tl_stream = the group's stream)
+static int group_issue(mi_ctx* c, int g, const GroupJob& j) {
+    const int E = c->E, ng = E / c->n_groups, e0 = g * ng;
+    hipStream_t st = tl_stream;
+    char* ring = c->frames ? (char*)c->frames : (char*)c->obsf;
+    if (j.frames) HIPC(hipMemcpyAsync(ring + ((size_t)j.t * E + e0) * c->obs_bytes_per_env, j.frames, j.bytes, hipMemcpyHostToDevice, st));
+    float* h_rd = c->h_rd + 2 * e0;      // this group's {rew[ng], done[ng]} (pinned, device-visible), filled by the submitting thread
+    if (j.have_rd && c->gru_on) HIPC(hipMemcpyAsync(c->d_done + e0, h_rd + ng, (size_t)ng * 4, hipMemcpyHostToDevice, st));
+    const float* du = nullptr;
+    if (j.u) { HIPC(hipMemcpyAsync(c->d_u + e0, j.u, (size_t)ng * 4, hipMemcpyHostToDevice, st)); du = c->d_u + e0; }
+    InputSrc src{c->frames ? (const void*)c->frames : (const void*)c->obsf, nullptr, (long long)j.t * E + e0};
+    net_forward(c, src, ng, true, false, false, e0);
+    const size_t o = (size_t)j.t * E + e0;
+    launch_heads_sample(c->feat + (size_t)e0 * c->H, c->params + c->wh_off, c->params + c->bh_off, ng, c->H, c->A, du, j.seed, (unsigned long long)j.t * E + e0,
+                        j.last ? nullptr : c->act + o, j.last ? nullptr : c->logp + o, c->value + o, c->h_pack + 3 * e0, nullptr,
+                        j.have_rd ? h_rd : nullptr, j.have_rd ? c->rew + o - E : nullptr, j.have_rd ? c->done + o - E : nullptr, st,
+                        c->d_done_ctr + 1 + g, c->h_flag + 1 + g, j.ticket);
+    HIPC(hipGetLastError());
+    return 0;
+}
+static void group_worker_main(mi_ctx* c, int g) {
+    GroupWorker* w = c->gw[g];
+    hipSetDevice(c->cfg.device);
+    tl_stream = c->gs[g];
+    tl_ws_floats = c->gemm_ws_floats / mi_ctx::MAX_GROUPS; tl_ws = c->gemm_ws + (size_t)g * tl_ws_floats;     // concurrent groups: disjoint split-K slabs
+    unsigned seen = 0;
+    for (;;) {
+        int spins = 0;
+        while (w->posted.load(std::memory_order_acquire) == seen && !w->quit.load()) {
+            if (++spins < 40000) __builtin_ia32_pause();
+            else {                                   // idle for a few hundred us (update phase): sleep until the next post
+                std::unique_lock<std::mutex> lk(w->mu);
+                w->sleeping.store(true);
+                w->cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return w->posted.load() != seen || w->quit.load(); });
+                w->sleeping.store(false);
+                spins = 0;
+            }
+        }
+        if (w->quit.load()) return;
+        seen = w->posted.load(std::memory_order_acquire);
+        w->rc = group_issue(c, g, w->job);
+        if (w->rc) w->err = g_err;
+        w->done.store(seen, std::memory_order_release);
+    }
 }
 
 int mi_rollout_groups(mi_ctx* c, int32_t n_groups) {
@@ -1029,6 +1121,8 @@ int mi_rollout_groups(mi_ctx* c, int32_t n_groups) {
             HIPC(hipStreamCreateWithFlags(&c->gs[g], hipStreamNonBlocking));
             HIPC(hipEventCreateWithFlags(&c->ev_fork[g], hipEventDisableTiming));
             HIPC(hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming));
+            c->gw[g] = new GroupWorker();
+            c->gw[g]->th = std::thread(group_worker_main, c, g);
         }
     c->n_groups = n_groups;
     return 0;
@@ -1042,40 +1136,21 @@ int mi_rollout_submit(mi_ctx* c, int32_t t, int32_t g, const void* frames, size_
     const int E = c->E, ng = E / c->n_groups, e0 = g * ng;
     ARG(!frames || bytes == (size_t)ng * c->obs_bytes_per_env, "frames byte count != (E / groups) * bytes_per_env");
     if (rew_prev || done_prev) ARG(rew_prev && done_prev && t >= 1, "rew_prev/done_prev come together and belong to step t-1");
-    hipStream_t st = c->gs[g];
+    GroupWorker* w = c->gw[g];
+    worker_drain(w);
     if (!c->g_forked[g]) {               // first step since the main stream last worked: parameters / packed banks must be in place
         fc_refresh(c);
         HIPC(hipEventRecord(c->ev_fork[g], c->main_stream));
-        HIPC(hipStreamWaitEvent(st, c->ev_fork[g], 0));
+        HIPC(hipStreamWaitEvent(c->gs[g], c->ev_fork[g], 0));
         c->g_forked[g] = true;
     }
     c->groups_live = true; c->g_dirty[g] = true;
-    char* ring = c->frames ? (char*)c->frames : (char*)c->obsf;
-    if (frames) HIPC(hipMemcpyAsync(ring + ((size_t)t * E + e0) * c->obs_bytes_per_env, frames, bytes, hipMemcpyHostToDevice, st));
-    float* h_rd = c->h_rd + 2 * e0;      // this group's {rew[ng], done[ng]} (pinned, device-visible)
     const bool have_rd = rew_prev != nullptr;
-    if (have_rd) {
-        memcpy(h_rd, rew_prev, (size_t)ng * 4); memcpy(h_rd + ng, done_prev, (size_t)ng * 4);
-        if (c->gru_on) HIPC(hipMemcpyAsync(c->d_done + e0, h_rd + ng, (size_t)ng * 4, hipMemcpyHostToDevice, st));
-    }
-    const float* du = nullptr;
-    if (u) { HIPC(hipMemcpyAsync(c->d_u + e0, u, (size_t)ng * 4, hipMemcpyHostToDevice, st)); du = c->d_u + e0; }
+    if (have_rd) { float* h_rd = c->h_rd + 2 * e0; memcpy(h_rd, rew_prev, (size_t)ng * 4); memcpy(h_rd + ng, done_prev, (size_t)ng * 4); }
     const bool last = (t == c->T);
-    {
-        // issue this group's pass on its stream, with its slice of the split-K workspace (two groups' GEMMs run concurrently)
-        struct Scope { mi_ctx* c; hipStream_t s; float* w; size_t wf; ~Scope() { c->stream = s; c->gemm_ws = w; c->gemm_ws_floats = wf; } } sc{c, c->stream, c->gemm_ws, c->gemm_ws_floats};
-        const size_t slice = c->gemm_ws_floats / mi_ctx::MAX_GROUPS;
-        c->stream = st; c->gemm_ws = sc.w + (size_t)g * slice; c->gemm_ws_floats = slice;
-        c->prof.phase = 0;
-        InputSrc src{c->frames ? (const void*)c->frames : (const void*)c->obsf, nullptr, (long long)t * E + e0};
-        net_forward(c, src, ng, true, false, false, e0);
-        const size_t o = (size_t)t * E + e0;
-        launch_heads_sample(c->feat + (size_t)e0 * c->H, c->params + c->wh_off, c->params + c->bh_off, ng, c->H, c->A, du, seed, (unsigned long long)t * E + e0,
-                            last ? nullptr : c->act + o, last ? nullptr : c->logp + o, c->value + o, c->h_pack + 3 * e0, nullptr,
-                            have_rd ? h_rd : nullptr, have_rd ? c->rew + o - E : nullptr, have_rd ? c->done + o - E : nullptr, st,
-                            c->d_done_ctr + 1 + g, c->h_flag + 1 + g, ++c->g_ticket[g]);
-    }
-    HIPC(hipGetLastError()); NETCHK(c);
+    w->job = GroupJob{t, frames, bytes, have_rd, last, u, seed, ++c->g_ticket[g]};
+    w->posted.fetch_add(1, std::memory_order_seq_cst);
+    if (w->sleeping.load()) { { std::lock_guard<std::mutex> lk(w->mu); } w->cv.notify_one(); }
     c->g_busy[g] = true; c->g_last[g] = last;
     return 0;
 }
@@ -1085,14 +1160,18 @@ int mi_rollout_wait(mi_ctx* c, int32_t g, int64_t* act_out, float* logp_out, flo
     const int ng = c->E / c->n_groups, e0 = g * ng;
     const unsigned want = c->g_ticket[g];
     volatile unsigned* flag = c->h_flag + 1 + g;
+    GroupWorker* w = c->gw[g];
     bool seen = false;
     for (unsigned long long spin = 0; spin < (1ull << 34); ++spin) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
         __builtin_ia32_pause();
-        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(c->gs[g]) != hipErrorNotReady) break;     // finished without a ticket, or failed
+        if ((spin & 0xfffff) == 0xfffff && w->done.load() == w->posted.load() && hipStreamQuery(c->gs[g]) != hipErrorNotReady) break;   // issued, finished, no ticket: failed
     }
+    worker_drain(w);
     c->g_busy[g] = false;
+    if (w->rc) { const int rc = w->rc; w->rc = 0; return fail(rc, "group worker: " + w->err); }
     if (!seen) HIPC(hipStreamSynchronize(c->gs[g]));
+    NETCHK(c);
     const float* pk = c->h_pack + 3 * e0;
     const bool last = c->g_last[g];
     for (int e = 0; e < ng; ++e) {
@@ -1716,6 +1795,9 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
     for (void* q : fr) if (q) hipFree(q);
     return 0;
 }
+
+// bit 0: run rollout-sized bf16 inference passes on the separate block-2 / block-3 kernels instead of the fused launch (parity A/B)
+int mi_debug_flags(mi_ctx* c, int32_t flags) { ARG(c, "null"); JOIN(c); c->rollout_tail = !(flags & 1); return 0; }
 
 // Read back what the last training-mode pass (mi_minibatch) left in the activation buffers, as fp32 NHWC: which = 8 * block + k with
 // k = 0 P0 (pooled map), 1 A1, 2 P1, 3 A2, 4 P2 (res1.conv1 out, res1 out, res2.conv1 out, block out), 5 the max-pool arg-max bytes
