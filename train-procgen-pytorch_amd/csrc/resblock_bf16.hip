@@ -902,6 +902,253 @@ __global__ __launch_bounds__(C::NT, C::NT == 256 ? 2 : 1) void resblock_bwd_full
             for (int r = 0; r < 4; ++r) sl[C::WLEN + cb * 16 + kq * 4 + r] = accb[cb][r];
     }
 }
+// ---- wave-specialised variant (HW = 16, 512 threads).  The kernel above is LDS-bandwidth-bound in its conv phases: with one or two
+// 16-pixel tiles per wave every wave re-reads the whole filter bank (18 x 1 KB per conv and wave: 288 of the 738 KB an item reads),
+// i.e. ~1.5 operand reads per MFMA, 6 LDS cycles against 16 MFMA cycles with eight waves on one LDS pipe.  Here the eight waves take
+// two ROLES: waves 0-3 (one per SIMD) run the two transposed convs with BOTH filter banks in registers (2 x 18 fragments = 144 VGPRs,
+// loaded once per launch: no weight reads at all), waves 4-7 run the weight gradients (conv2's while the conv waves produce da,
+// conv1's while they produce dx); each SIMD hosts one wave of each role, so matrix work of one overlaps the LDS work of the other.
+// Per item: LDS reads 738 -> 370 KB, same MFMA count, same three barriers.  Arithmetic per output element and per slab entry is
+// unchanged (same K order, same pixel-step order): results are bit-identical to the kernel above.
+#ifdef WG_TIMING      // scratch/kbench_rb.hip: per-phase shader-clock totals of wave 0 (conv role, slots 0-3) and wave 4 (weight-gradient role, 4-7)
+__device__ unsigned long long g_rb_timing[8];
+#define RTCK(k) do { if ((tid & 255) == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
+#else
+#define RTCK(k) do { } while (0)
+#endif
+template <class C>
+__global__ __launch_bounds__(512, 2) void resblock_bwd_full32s_bf16_kernel(RbFullArgs a) {
+    static_assert(C::NT == 512 && C::HW == 16, "16x16 images, 8 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_x = smem_h;                         // dy rows ty0-2 .. ty0+TH+1
+    unsigned short* s_y = s_x + C::X_ELEMS;               // d(conv1 output) rows ty0-1 .. ty0+TH
+    unsigned short* s_a = s_y + C::Y_ELEMS;               // relu(conv1 output), same rows
+    unsigned short* s_p = s_a + C::Y_ELEMS;               // relu(block input), same rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool conv_role = wv < 4;
+#ifdef WG_TIMING
+    long long tacc_[4] = {0, 0, 0, 0}, tlast_ = clock64();
+#endif
+    const int rw = wv & 3;                                // index inside the role
+    for (int e = tid; e < (C::X_ELEMS + 3 * C::Y_ELEMS) / 8; e += C::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
+    // Per-wave persistent state, ONE register array for both roles (a kernel's registers are allocated for the union of what its
+    // waves may keep live: two separate sets spilled 471 registers).  conv role: st[2m + nb] = B fragment (tap m, output block nb) of
+    // conv2's transposed bank, st[18 + 2m + nb] of conv1's.  weight-gradient role: st[2qq + cb] / st[10 + 2qq + cb] = accumulator
+    // tiles of conv2 / conv1 for this wave's column qq and output block cb, st[20 + cb] = bias accumulators (rw 2: conv2, rw 3: conv1).
+    f32x4 st[36];
+    constexpr int QM = 5;
+    const int qcnt = (C::NQ - rw + 3) / 4;                // columns q = rw + 4 * qq of the 18 (tap, input block) columns: 5, 5, 4, 4
+    if (conv_role) {
+#pragma unroll
+        for (int m = 0; m < 9; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                st[2 * m + nb] = __builtin_bit_cast(f32x4, *(const uint4*)(a.bank2_t + (nb * 16 + i) * C::WS + m * 32 + kq * 8));
+                st[18 + 2 * m + nb] = __builtin_bit_cast(f32x4, *(const uint4*)(a.bank1_t + (nb * 16 + i) * C::WS + m * 32 + kq * 8));
+            }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 36; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};      // accumulators (0 .. 21); 22 .. 30 are the prefetch words
+    }
+    // Drain the 36 fragment loads HERE.  Otherwise the compiler, which sees one register array, guards every first touch of st[k] inside
+    // the loop with a counted s_waitcnt vmcnt(35 - k): harmless for the conv waves, but the weight-gradient waves have their nine
+    // prefetch loads in flight at that point, and vmcnt(N < 9) in the middle of their MFMA stream waits for HBM on every item.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0), lgkmcnt / expcnt untouched
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    auto koffc = [](int m) { return ((m / 3) * C::P + (m % 3)) * C::S; };
+
+    const int nwork = a.n * C::TPI;
+    // Staging (global -> registers one item ahead -> LDS) is the weight-gradient waves' job: their half of st has room for the nine
+    // prefetch words (st[22 .. 30]), the conv waves' half is full of filter fragments.  t2 = thread index among those 256 threads.
+    constexpr int NT2 = 256, KX2 = (C::NX + NT2 - 1) / NT2, KA2 = (C::NA + NT2 - 1) / NT2;
+    static_assert(22 + KX2 + 2 * KA2 <= 36, "prefetch words fit the state array");
+    const int t2 = tid - 256;
+    auto load = [&](int work) {
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+#pragma unroll
+        for (int k = 0; k < KX2; ++k) {
+            const int e = t2 + k * NT2;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (e < C::NX) { const int c8 = e & 3, px = (e >> 2) % C::HW, gy = ty0 - 2 + e / (4 * C::HW);
+                             if (gy >= 0 && gy < C::HW) v = *(const uint4*)(a.dy + ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8); }
+            st[22 + k] = __builtin_bit_cast(f32x4, v);
+        }
+#pragma unroll
+        for (int k = 0; k < KA2; ++k) {
+            const int e = t2 + k * NT2;
+            uint4 va = {0u, 0u, 0u, 0u}, vp = {0u, 0u, 0u, 0u};
+            if (e < C::NA) { const int c8 = e & 3, px = (e >> 2) % C::HW, gy = ty0 - 1 + e / (4 * C::HW);
+                             if (gy >= 0 && gy < C::HW) { const long long o = ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8;
+                                                          va = *(const uint4*)(a.a_fwd + o); vp = *(const uint4*)(a.x_fwd + o); } }
+            st[22 + KX2 + k] = __builtin_bit_cast(f32x4, va); st[22 + KX2 + KA2 + k] = __builtin_bit_cast(f32x4, vp);
+        }
+    };
+    // one pixel step (32 pixels) of a layer's weight gradient: d = the layer's output-gradient tile, src = its (ReLU'd) input tile
+    auto wg_step = [&](int t, const unsigned short* s_d, int d_off, const unsigned short* s_src, const int a0, bool bias) {
+        int orow[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pl = 32 * t + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq;
+            orow[h] = ((pl / C::HW) * C::P + pl % C::HW) * C::S + 4 * cp;
+        }
+        auto tr = [&](const unsigned short* base, int off) {
+            const rb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + orow[0] + off));
+            const rb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + orow[1] + off));
+            return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        // all operand reads of the step go out before its first MFMA: with one column's read in flight the MFMA stream runs at the
+        // LDS latency (200+ cycles with eight waves on the pipe) instead of 32 cycles per column
+        bf16x8 d[2], b[QM];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) d[cb] = tr(s_d, d_off + cb * 16);
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq) {
+            const int q = rw + 4 * (qq < 4 ? qq : (qcnt > 4 ? 4 : 0)), tap = q >> 1, ib = q & 1;
+            b[qq] = tr(s_src, ((tap / 3) * C::P + (tap % 3)) * C::S + ib * 16);
+        }
+        asm volatile("" ::: "memory");
+        if (bias) { st[20] = MFMA_BF16(d[0], ones, st[20]); st[21] = MFMA_BF16(d[1], ones, st[21]); }
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq)
+            if (qq < qcnt) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) st[a0 + 2 * qq + cb] = MFMA_BF16(d[cb], b[qq], st[a0 + 2 * qq + cb]);
+            }
+    };
+
+    if (!conv_role && (int)blockIdx.x < nwork) load(blockIdx.x);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+        __syncthreads();
+        RTCK(3);                                            // phase-2 work + wait at the top barrier
+        if (!conv_role) {
+#pragma unroll
+            for (int k = 0; k < KX2; ++k) {
+                const int e = t2 + k * NT2;
+                if (e < C::NX) *(uint4*)(s_x + ((e / (4 * C::HW)) * C::P + (e >> 2) % C::HW + 1) * C::S + (e & 3) * 8) = __builtin_bit_cast(uint4, st[22 + k]);
+            }
+#pragma unroll
+            for (int k = 0; k < KA2; ++k) {
+                const int e = t2 + k * NT2;
+                if (e < C::NA) {
+                    const int o = ((e / (4 * C::HW)) * C::P + (e >> 2) % C::HW + 1) * C::S + (e & 3) * 8;
+                    const uint4 va = __builtin_bit_cast(uint4, st[22 + KX2 + k]), vp = __builtin_bit_cast(uint4, st[22 + KX2 + KA2 + k]);
+                    *(uint4*)(s_a + o) = (uint4){rb_relu2(va.x), rb_relu2(va.y), rb_relu2(va.z), rb_relu2(va.w)};
+                    *(uint4*)(s_p + o) = (uint4){rb_relu2(vp.x), rb_relu2(vp.y), rb_relu2(vp.z), rb_relu2(vp.w)};
+                }
+            }
+        }
+        __syncthreads();
+        RTCK(0);                                            // staging (+ the conv waves' wait for it)
+        if (!conv_role && work + (int)gridDim.x < nwork) load(work + gridDim.x);
+
+        if (conv_role) {
+            // ---- da = convT2(dy) * (a > 0) on rows ty0-1 .. ty0+TH -> s_y: tiles rw, rw+4, rw+8 of the 10 (weights in registers), two
+            // tiles at a time: four independent accumulator chains keep the matrix pipe busy through the MFMA latency
+            for (int t = rw; t < C::NMT1; t += 4) {            // one tile at a time: its nine operand reads go out together, then 18 MFMAs
+                const int pl = t * 16 + i, px = pl % C::HW, ry = pl / C::HW;
+                const unsigned short* src = s_x + (ry * C::P + px) * C::S + kq * 8;
+                const int yb = (ry * C::P + px + 1) * C::S + kq * 4;
+                bf16x8 av[5];                                   // reads go out in batches of 5 + 4 taps (all nine at once spill)
+#pragma unroll
+                for (int m = 0; m < 5; ++m) av[m] = *(const bf16x8*)(src + koffc(m));
+                const uint2 mk0 = *(const uint2*)(s_a + yb), mk1 = *(const uint2*)(s_a + yb + 16);
+                asm volatile("" ::: "memory");
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int m = 0; m < 9; ++m) {
+                    const bf16x8 cur = av[m % 5];
+                    acc[0] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[2 * m]), cur, acc[0]);
+                    acc[1] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[2 * m + 1]), cur, acc[1]);
+                    if (m < 4) av[m] = *(const bf16x8*)(src + koffc(m + 5));        // slot m is free again: taps 5..8 follow behind
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const uint2 mk = nb ? mk1 : mk0;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rb_lane(mk, r) > 0.f ? acc[nb][r] : 0.f;
+                    const uint2 raw = rb_pack(v);
+                    *(uint2*)(s_y + yb + nb * 16) = raw;
+                    if (a.da_out) {
+                        const int gy = ty0 - 1 + ry;
+                        if (ry >= 1 && ry <= C::TH) *(uint2*)(a.da_out + ((img * C::HW + gy) * C::HW + px) * C::C + nb * 16 + kq * 4) = raw;
+                    }
+                }
+            }
+        } else {
+            // ---- conv2's weight / bias gradient from (dy, relu(a)): needs nothing the conv waves are producing
+#pragma unroll
+            for (int t = 0; t < C::NSTEP; ++t) wg_step(t, s_x, (2 * C::P + 1) * C::S, s_a, 0, rw == 2);
+        }
+        RTCK(1);                                            // phase-1 work
+        __syncthreads();
+        RTCK(2);                                            // wait for the other role
+        if (conv_role) {
+            // ---- dx = convT1(da) * (x > 0) + dy on rows ty0 .. ty0+TH-1 -> HBM: tiles rw, rw+4 of the 8, one at a time as above
+            for (int t = rw; t < C::NMT2; t += 4) {
+                const int pl = t * 16 + i, px = pl % C::HW, oy = pl / C::HW;
+                const unsigned short* src = s_y + (oy * C::P + px) * C::S + kq * 8;
+                bf16x8 av[5];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) av[m] = *(const bf16x8*)(src + koffc(m));
+                const int eo = ((oy + 1) * C::P + px + 1) * C::S + kq * 4;
+                const uint2 mk0 = *(const uint2*)(s_p + eo), mk1 = *(const uint2*)(s_p + eo + 16);
+                const uint2 sk0 = *(const uint2*)(s_x + eo + C::P * C::S), sk1 = *(const uint2*)(s_x + eo + C::P * C::S + 16);
+                asm volatile("" ::: "memory");
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int m = 0; m < 9; ++m) {
+                    const bf16x8 cur = av[m % 5];
+                    acc[0] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[18 + 2 * m]), cur, acc[0]);
+                    acc[1] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[18 + 2 * m + 1]), cur, acc[1]);
+                    if (m < 4) av[m] = *(const bf16x8*)(src + koffc(m + 5));
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const uint2 mk = nb ? mk1 : mk0, sk = nb ? sk1 : sk0;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (rb_lane(mk, r) > 0.f ? acc[nb][r] : 0.f) + rb_lane(sk, r);
+                    *(uint2*)(a.dx_out + ((img * C::HW + ty0 + oy) * C::HW + px) * C::C + nb * 16 + kq * 4) = rb_pack(v);
+                }
+            }
+        } else {
+            // ---- conv1's weight / bias gradient from (da, relu(x))
+#pragma unroll
+            for (int t = 0; t < C::NSTEP; ++t) wg_step(t, s_y, (C::P + 1) * C::S, s_p, 10, rw == 3);
+        }
+    }
+#ifdef WG_TIMING
+    if ((tid & 255) == 0) for (int q = 0; q < 4; ++q) atomicAdd(&g_rb_timing[(tid >> 8) * 4 + q], (unsigned long long)tacc_[q]);
+#endif
+    // ---- the weight-gradient waves own their columns: straight to the slabs (layout as the kernel above)
+    if (!conv_role) {
+        float* sl2 = a.slab2 + (long long)blockIdx.x * C::SLAB;
+        float* sl1 = a.slab1 + (long long)blockIdx.x * C::SLAB;
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq)
+            if (qq < qcnt) {
+                const int q = rw + 4 * qq, tap = q >> 1, ib = q & 1;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = ((cb * 16 + kq * 4 + r) * 9 + tap) * C::C + ib * 16 + i;
+                        sl2[o] = st[2 * qq + cb][r]; sl1[o] = st[10 + 2 * qq + cb][r];
+                    }
+            }
+        if (i == 0 && rw >= 2) {
+            float* sl = rw == 2 ? sl2 : sl1;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sl[C::WLEN + cb * 16 + kq * 4 + r] = st[20 + cb][r];
+        }
+    }
+}
+
 template <class C>
 static int rb_full32_grid_t(int n) {
     int bpc = (int)((160 * 1024) / C::LDS_BYTES);
@@ -918,12 +1165,25 @@ static void launch_rb_full32_t(const RbFullArgs& a, hipStream_t st) {
     if (grid < 1) return;
     hipLaunchKernelGGL(resblock_bwd_full32_bf16_kernel<C>, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, a);
 }
+#ifndef RB32_SPECIALISED
+#define RB32_SPECIALISED 1
+#endif
+static void launch_rb_full32s(const RbFullArgs& a, hipStream_t st) {
+    using C = RbFull32;
+    constexpr size_t LDS = (size_t)(C::X_ELEMS + 3 * C::Y_ELEMS) * 2;          // no bank copies in LDS
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)resblock_bwd_full32s_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    const int grid = rb_full32_grid_t<C>(a.n);                                  // same grid = same slab count as the plain kernel
+    if (grid < 1) return;
+    hipLaunchKernelGGL(resblock_bwd_full32s_bf16_kernel<C>, dim3(grid), dim3(512), LDS, st, a);
+}
 // 32-channel residual blocks @16x16 (CS_32_32_16) and @8x8 (CS_32_32_8).  slab2 / slab1: [grid][9248] floats each.
 void launch_resblock_bwd_full32_bf16(ConvShape s, const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
                                      const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st) {
     RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
                  bank2_t, bank1_t, slab2, slab1, n};
-    if (s == CS_32_32_16) launch_rb_full32_t<RbFull32>(a, st); else if (s == CS_32_32_8) launch_rb_full32_t<RbFull32S>(a, st);
+    if (s == CS_32_32_16) { if (RB32_SPECIALISED) launch_rb_full32s(a, st); else launch_rb_full32_t<RbFull32>(a, st); }
+    else if (s == CS_32_32_8) launch_rb_full32_t<RbFull32S>(a, st);
 }
 
 // res1 + res2 of a block forward in one launch.  b / bank: res1.conv1, res1.conv2, res2.conv1, res2.conv2 (forward banks).
