@@ -120,37 +120,45 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
     static_assert(S32 == 48, "KoffC assumes the 32-channel pixel stride");
     const int bb16 = i * WS16 + kq * 8, bb32 = i * WS32 + kq * 8;
 
-    for (int e = tid; e < 320; e += NT) s_b[e] = a.bias[e >> 5][e & 31];
-    // bank k lives in buffer k & 1: fetched into registers at the start of conv k - 1, written to LDS at its end
-    uint4 wreg[KW];
+    // Bank k lives in LDS buffer k & 1 and travels through register set k & 1: fetched TWO convs ahead of its use (a conv phase is
+    // ~0.5 us, an L2 round trip ~1 us: one conv of lead left every commit waiting for its loads), written to LDS at the end of conv k - 1.
+    uint4 wreg[2][KW];
     auto bank_fetch = [&](int k) {
         const int words = (k == 0 ? 32 * WS16 : W_ELEMS) / 8;
 #pragma unroll
-        for (int q = 0; q < KW; ++q) { const int e = tid + q * NT; wreg[q] = e < words ? ((const uint4*)a.bank[k])[e] : (uint4){0u, 0u, 0u, 0u}; }
+        for (int q = 0; q < KW; ++q) { const int e = tid + q * NT; wreg[k & 1][q] = e < words ? ((const uint4*)a.bank[k])[e] : (uint4){0u, 0u, 0u, 0u}; }
     };
     auto bank_commit = [&](int k) {
         const int words = (k == 0 ? 32 * WS16 : W_ELEMS) / 8;
 #pragma unroll
-        for (int q = 0; q < KW; ++q) { const int e = tid + q * NT; if (e < words) ((uint4*)s_w[k & 1])[e] = wreg[q]; }
+        for (int q = 0; q < KW; ++q) { const int e = tid + q * NT; if (e < words) ((uint4*)s_w[k & 1])[e] = wreg[k & 1][q]; }
     };
-    bank_fetch(0); bank_commit(0);
+    // end of conv c (c >= 1): bank c + 1 goes to LDS (its buffer's previous bank, c - 1, was last read in conv c - 1), bank c + 3 is requested
+    auto bank_step = [&](int c) { bank_commit(c + 1); if (c + 3 <= 9) bank_fetch(c + 3); };
 
     for (int img = blockIdx.x; img < a.n; img += gridDim.x) {
-        __syncthreads();                                    // (a second image of this workgroup: everyone is done with the previous one)
-        // ---- stage the 32x32x16 image (haloed, zero borders); clear the first residual image
-        for (int e = tid; e < (IN_ELEMS + X16_ELEMS) / 8; e += NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};
-        if (img != (int)blockIdx.x) { bank_fetch(0); bank_commit(0); }
-        __syncthreads();
+        // ---- every first load of the image is requested before anything waits: the frame (4 words per thread), banks 0 / 1, the biases
+        uint4 xin[2048 / NT];
         {
             const uint4* g = (const uint4*)(a.x + (long long)img * 32 * 32 * 16);
 #pragma unroll
-            for (int q = 0; q < 2048 / NT; ++q) {           // 2048 words of 8 channels: (row, col, half)
-                const int e = tid + q * NT, c8 = e & 1, px = (e >> 1) & 31, r = e >> 6;
-                *(uint4*)(s_in + ((r + 1) * P32 + px + 1) * S16 + c8 * 8) = g[e];
-            }
+            for (int q = 0; q < 2048 / NT; ++q) xin[q] = g[tid + q * NT];
         }
+        bank_fetch(0); bank_fetch(1);
+        const float bias_v = tid < 320 ? a.bias[tid >> 5][tid & 31] : 0.f;
+        __syncthreads();                                    // (a second image of this workgroup: everyone is done with the previous one)
+        // ---- stage the 32x32x16 image (haloed, zero borders); clear the first residual image
+        for (int e = tid; e < (IN_ELEMS + X16_ELEMS) / 8; e += NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};
         for (int e = tid; e < 9 * 16; e += NT) ((unsigned*)s_y)[(e >> 4) * 33 * (SCS / 2) + (e & 15)] = MI_KEY_MIN2;      // pad cell (column -1) of the 9 key rows
-        bank_fetch(1);
+        if (tid < 320) s_b[tid] = bias_v;
+        bank_commit(0);
+        bank_fetch(2);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2048 / NT; ++q) {               // 2048 words of 8 channels: (row, col, half)
+            const int e = tid + q * NT, c8 = e & 1, px = (e >> 1) & 31, r = e >> 6;
+            *(uint4*)(s_in + ((r + 1) * P32 + px + 1) * S16 + c8 * 8) = xin[q];
+        }
         __syncthreads();
 
         // ================= block2.conv (16 -> 32 @32x32) + MaxPool2d(3,2,1), four bands of 4 pooled rows -> s_x (16x16x32, haloed)
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
                     *(uint2*)(s_y + cbase[mt] + nb * 16) = (uint2){dead[mt] ? MI_KEY_MIN2 : k0, dead[mt] ? MI_KEY_MIN2 : k1};
                 }
             }
-            if (band == 0) bank_commit(1);
+            if (band == 0) { bank_commit(1); bank_fetch(3); }
             __syncthreads();
             if (tid < 256) {                                // (pooled row 0..3, pooled col, 8-channel group)
                 const int c8 = tid & 3, ox = (tid >> 2) & 15, oyl = tid >> 6;
@@ -211,7 +219,6 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
             for (int st = 0; st < 2; ++st) {
                 const int k1 = 1 + 2 * st, k2 = k1 + 1;
                 f32x4 acc[MT16][2];
-                bank_fetch(k2);
                 rt_conv<9, WS32, true, MT16, KoffC<P16>>(s_x, s_w[k1 & 1], KoffC<P16>(), abase, bb32, acc);
 #pragma unroll
                 for (int mt = 0; mt < MT16; ++mt)
@@ -224,9 +231,8 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
                         const uint2 raw = rt_pack(v);
                         *(uint2*)(s_y + cen[mt] + nb * 16) = (uint2){rt_relu2(raw.x), rt_relu2(raw.y)};
                     }
-                bank_commit(k2);
+                bank_step(k1);
                 __syncthreads();
-                bank_fetch(k2 + 1);
                 rt_conv<9, WS32, false, MT16, KoffC<P16>>(s_y, s_w[k2 & 1], KoffC<P16>(), abase, bb32, acc);
 #pragma unroll
                 for (int mt = 0; mt < MT16; ++mt)
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
                         for (int r = 0; r < 4; ++r) v[r] = acc[mt][nb][r] + bq[r] + rt_lane(sk, r);
                         *(uint2*)(s_x + cen[mt] + nb * 16) = rt_pack(v);           // raw: the next conv applies the ReLU on its operand reads
                     }
-                bank_commit(k2 + 1);
+                bank_step(k2);
                 __syncthreads();
             }
         }
@@ -259,7 +265,6 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
 #pragma unroll
             for (int mt = 0; mt < MT16; ++mt) { const int pl = (wave + NW * mt) * 16 + i, y = pl >> 4, x = pl & 15; abase[mt] = (y * P16 + x) * S32 + kq * 8; cbase[mt] = ((y + 1) * 17 + x + 1) * SCS + kq * 4; }
             f32x4 acc[MT16][2];
-            bank_fetch(6);
             rt_conv<9, WS32, false, MT16, KoffC<P16>>(s_x, s_w[5 & 1], KoffC<P16>(), abase, bb32, acc);
 #pragma unroll
             for (int mt = 0; mt < MT16; ++mt)
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
                     const unsigned k1 = mi_bf16x2_to_keys(mi_pk_bf16(acc[mt][nb][2] + bq[2], acc[mt][nb][3] + bq[3]));
                     *(uint2*)(s_k3 + cbase[mt] + nb * 16) = (uint2){k0, k1};
                 }
-            bank_commit(6);
+            bank_step(5);
             __syncthreads();
             for (int e = tid; e < X8_ELEMS / 8; e += NT) ((uint4*)s_y8)[e] = (uint4){0u, 0u, 0u, 0u};       // s_x (16x16) is dead from here
             if (tid < 256) {
@@ -297,7 +302,6 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const int k1 = 6 + 2 * st, k2 = k1 + 1;
-                bank_fetch(k2);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (on) acc = rt_conv1<true>(s_x8, s_w[k1 & 1], abase, bbn);
                 if (on) {
@@ -308,9 +312,8 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
                     const uint2 raw = rt_pack(v);
                     *(uint2*)(s_y8 + cen) = (uint2){rt_relu2(raw.x), rt_relu2(raw.y)};
                 }
-                bank_commit(k2);
+                bank_step(k1);
                 __syncthreads();
-                if (k2 < 9) bank_fetch(k2 + 1);
                 if (on) acc = rt_conv1<false>(s_y8, s_w[k2 & 1], abase, bbn);
                 if (on) {
                     const f32x4 bq = *(const f32x4*)(s_b + k2 * 32 + nb * 16 + kq * 4);
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
                     if (k2 < 9) *(uint2*)(s_x8 + cen) = raw;
                     else *(uint2*)(a.y + ((long long)img * 64 + pl) * 32 + nb * 16 + kq * 4) = raw;
                 }
-                if (k2 < 9) bank_commit(k2 + 1);
+                if (k2 < 9) bank_step(k2);
                 __syncthreads();
             }
         }
