@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < reps; ++r) run();
     hipEventRecord(e1, st); hipStreamSynchronize(st);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const int grid = rb_full32_grid_t<RbFull32>(n);
+    const int grid = RB32_SPECIALISED && spec ? rb_full32s_grid(n) : rb_full32_grid_t<RbFull32>(n);
     printf("%s n=%d grid=%d: %.1f us/launch  (%s)\n", spec ? "specialised" : "plain", n, grid, ms * 1000 / reps, hipGetErrorString(hipGetLastError()));
 #ifdef WG_TIMING
     if (spec) {

@@ -9,6 +9,7 @@
 // (lane quarter kq owns channels 8kq..8kq+7); for 16 input channels it is two taps (kq>>1 selects the tap,
 // kq&1 the 8-channel half), the 10th "tap" being a zero column of the filter bank.
 #include "common.h"
+#include <type_traits>
 
 static int c1_grid(int n);          // persistent grid of the block1.conv weight-gradient kernel (defined with it)
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -62,9 +63,14 @@ struct PoolStage {
     // s_dst[((y - y_base) * dst_pw + x + xoff) * S + channel]
     static __device__ __forceinline__ void gather(const unsigned short* s_pd, int a0, int y_lo, int y_hi, unsigned short* s_dst, int y_base,
                                                   int dst_pw, int xoff, int S) {
+        for (int task = threadIdx.x; task < NTASK; task += 256) gather_task(s_pd, task, a0, y_lo, y_hi, s_dst, y_base, dst_pw, xoff, S);
+    }
+    static constexpr int NTASK = (NPR - 1) * HO * (CH / 4);               // 2x2-pixel blocks x 4-channel groups of one staged item
+    static __device__ __forceinline__ void gather_task(const unsigned short* s_pd, int task, int a0, int y_lo, int y_hi, unsigned short* s_dst,
+                                                       int y_base, int dst_pw, int xoff, int S) {
         const uint8_t* s_pa = (const uint8_t*)(s_pd + PD_ELEMS);
         constexpr int Q = CH / 4;
-        for (int task = threadIdx.x; task < (NPR - 1) * HO * Q; task += 256) {
+        {
             const int cq = task % Q, bx = (task / Q) % HO, bl = task / (Q * HO);
             float sm[4][4];
 #pragma unroll
@@ -104,6 +110,47 @@ struct PoolStage {
                         (uint2){mi_pk_bf16(q[0], q[1]), mi_pk_bf16(q[2], q[3])};
                 }
             }
+        }
+    }
+    // the same sums for a 2x2-pixel block x 2 channels (twice the tasks: an even deal over 512 threads, fewer live registers)
+    static constexpr int NTASK2 = (NPR - 1) * HO * (CH / 2);
+    static __device__ __forceinline__ void gather_task2(const unsigned short* s_pd, int task, int a0, int y_lo, int y_hi, unsigned short* s_dst,
+                                                        int y_base, int dst_pw, int xoff, int S) {
+        const uint8_t* s_pa = (const uint8_t*)(s_pd + PD_ELEMS);
+        constexpr int Q = CH / 2;
+        const int cq = task % Q, bx = (task / Q) % HO, bl = task / (Q * HO);
+        float sm[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sm[q][0] = 0.f; sm[q][1] = 0.f; }
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int ox = bx + wx;
+                const int o = ((bl + wy) * HO + (ox < HO ? ox : HO - 1)) * CH + cq * 2;
+                const unsigned d = *(const unsigned*)(s_pd + o);
+                unsigned ag = *(const unsigned short*)(s_pa + o);
+                if (ox >= HO) ag = 0xffffu;                                    // window column HO does not exist
+                const float v[2] = {__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)};
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int ky = dy + 1 - 2 * wy, kx = dx + 1 - 2 * wx;
+                        if (ky < 0 || kx < 0) continue;
+                        const unsigned pos = (unsigned)(ky * 3 + kx);
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            sm[dy * 2 + dx][c] += (((ag >> (8 * c)) & 0xffu) == pos) ? v[c] : 0.f;
+                    }
+            }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int y = 2 * (a0 + bl) + dy;
+            if (y < y_lo || y >= y_hi) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                *(unsigned*)(s_dst + ((y - y_base) * dst_pw + 2 * bx + dx + xoff) * S + cq * 2) = mi_pk_bf16(sm[dy * 2 + dx][0], sm[dy * 2 + dx][1]);
         }
     }
 };
@@ -188,8 +235,17 @@ struct BfWg {                                                              // fo
     static constexpr int WLEN = CF_OUT * 9 * CF_IN, SLAB = WLEN + CF_OUT;
     static constexpr size_t RED_BYTES = (size_t)(WLEN + 4 * CF_OUT) * 4;
 };
+#ifdef BF_TIMING       // scratch/kbench_cb.hip: per-phase shader-clock totals of wave 0 of every workgroup (fused block2.conv backward)
+__device__ unsigned long long g_bf_timing[16];
+#define BTCK(k) do { if (WG && threadIdx.x == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
+#else
+#define BTCK(k) do { } while (0)
+#endif
 template <class C, bool POOLIN = false, bool WG = false>
 __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(ConvArgs a) {
+#ifdef BF_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_in = smem_h;
     unsigned short* s_w = smem_h + C::IN_ELEMS;
@@ -273,6 +329,7 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         bf_coords<C>(work, img0, ty0, tx0);
         __syncthreads();
+        BTCK(0);                                                           // epilogue stores + wait at the top barrier
         if constexpr (POOLIN) {
             ps.store(s_pd);
             if constexpr (WG) {
@@ -283,15 +340,19 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
                 }
             }
             __syncthreads();
+            BTCK(1);                                                       // staging stores (wait for the prefetched loads) + barrier
             PS::gather(s_pd, ty0 / 2 - 1, ty0 - 1, ty0 + C::TH + 1, s_in, ty0 - 1, C::PW, 1, C::S);
+            BTCK(2);                                                       // gather
         } else bf_tile_store<C>(regs, s_in, a.relu_in);
         __syncthreads();
+        BTCK(3);                                                           // barrier after the gather
         if (work + (int)gridDim.x < nwork) {
             int i2, y2, x2;
             bf_coords<C>(work + gridDim.x, i2, y2, x2);
             if constexpr (POOLIN) ps.load(g_in, a.pool_arg, i2, y2 / 2 - 1); else bf_tile_load<C>(regs, g_in, a.n, i2, y2, x2);
             xi_load(i2, y2);
         }
+        BTCK(4);                                                           // next item's loads issued
         if constexpr (WG) {            // weight gradient of the forward conv from the two LDS tiles; pixel steps of 32 dealt to the waves
             const int rq = (lane & 15) >> 2, cp = lane & 3;
             const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
@@ -321,6 +382,7 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
                 }
             }
         }
+        BTCK(5);                                                           // weight-gradient MFMAs
         // epilogue operands requested before the MFMA phase (one wave-uniform branch per block of loads)
         uint2 e_mask[C::MT][C::NB], e_res[C::MT][C::NB];
         long long e_off[C::MT];
@@ -381,6 +443,7 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
                 for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);
         }
 
+        BTCK(6);                                                           // data-gradient MFMAs
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
             if (e_on[mt]) {
@@ -400,6 +463,9 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
                 }
             }
     }
+#ifdef BF_TIMING
+    if (WG && threadIdx.x == 0) for (int q = 0; q < 8; ++q) atomicAdd(&g_bf_timing[q], (unsigned long long)tacc_[q]);
+#endif
     if constexpr (WG) {                // waves summed through LDS in fixed order; one slab per workgroup: [co_f][tap][ci_f] then the bias sums
         __syncthreads();
         float* red = (float*)smem_h;
@@ -430,6 +496,215 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
         for (int e = tid; e < W::WLEN; e += 256) slab[e] = red[e];
         if (tid < W::CF_OUT) slab[W::WLEN + tid] = (redb[tid] + redb[W::CF_OUT + tid]) + (redb[2 * W::CF_OUT + tid] + redb[3 * W::CF_OUT + tid]);
     }
+}
+
+// ------------------------------------------------------------------------------------------ block2.conv: whole backward in one launch
+// Data gradient AND weight / bias gradient of block2.conv (16 -> 32 channels @32x32) from the POOLED output gradient + arg-max
+// bytes, 512 threads per workgroup and two workgroups per CU = 4 waves per SIMD.  The 256-thread fused variant of the generic
+// kernel above measured 326 us per 8192 samples with every pipe under 55 % busy (scratch/kbench_cb.hip phase clocks: gather 32 %,
+// weight-gradient MFMAs 25 %, data-gradient MFMAs 20 % of an item, each phase latency-bound at 2 waves per SIMD), so this kernel
+// keeps the same LDS tiles and arithmetic but (a) doubles the waves per tile, (b) gives the staging / next-item loads to waves 4-7,
+// which own one gather task against two for waves 0-3, (c) addresses every global access as item base (scalar) + per-thread
+// constant offset, (d) splits the 20 weight-gradient accumulator tiles of a pixel step over a wave PAIR (taps 0-4 | taps 5-8 + bias)
+// so a wave holds 10 tiles instead of 20 (128-register budget).
+// Item = 8 conv rows x 32 columns of one image.  LDS: s_in [10][34][48] gathered conv-output gradient, s_w data-gradient filter
+// bank, s_pd 7 pooled rows (bf16 + arg bytes), s_xi [10][34][16] forward input.  Data gradient: same operand layout and K order as
+// the generic kernel -> bit-identical dX.  Weight gradient: pixel steps {2p, 2p+1} belong to the wave pair (p, p+4); partial sums
+// leave through LDS in fixed wave order, one slab per workgroup.
+#ifndef B2BWD_NEW
+#define B2BWD_NEW 1
+#endif
+struct B2Bwd {
+    using C = BfCfg<32, 16, 32, 8, 32, 1, true>;
+    using PS = PoolStage<32, 16, 6>;                                        // pooled rows 4k .. 4k+5 of item k
+    static constexpr int NT = 512;
+    static constexpr int IN_ROWS = C::PH + 1, IN_ELEMS = IN_ROWS * C::PW * C::S;       // conv rows ty0-1 .. ty0+9
+    static constexpr int ROW_WORDS = C::PW * C::S / 8;                      // 16-byte words of one staged gradient row
+    static constexpr int SX = 16, XI_ELEMS = C::PH * C::PW * SX;
+    static constexpr int NXI = C::PH * C::TW * 2, KXI = (NXI + NT - 1) / NT;           // 16-byte words of the forward-input tile (interior columns)
+    static constexpr int WLEN = 32 * 9 * 16, SLAB = WLEN + 32;
+    static constexpr int ONES_ELEMS = (C::PW + 8 + 1) * SX + 16;           // bf16 1.0s covering every offset a slot's four operand reads add
+    static constexpr size_t LDS = (size_t)(IN_ELEMS + C::W_ELEMS) * 2 + PS::BYTES + (size_t)(XI_ELEMS + ONES_ELEMS) * 2;
+    static_assert(LDS >= (size_t)(WLEN + 4 * 32) * 4, "the final reduction reuses the tile memory");
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    static_assert(PS::NW <= NT && PS::NTASK2 == 5 * 256, "one pooled-stage word per thread; 256 two-channel gather tasks per block row");
+};
+#ifdef BF_TIMING
+#define B2CK(k) do { if ((threadIdx.x & 255) == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
+#else
+#define B2CK(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(512, 4) void block2_conv_bwd_bf16_kernel(ConvArgs a) {
+    using K = B2Bwd; using C = K::C; using PS = K::PS;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_in = smem_h;
+    unsigned short* s_w = s_in + K::IN_ELEMS;
+    unsigned short* s_pd = s_w + C::W_ELEMS;
+    unsigned short* s_xi = s_pd + PS::PD_ELEMS + (PS::PD_ELEMS + 1) / 2;
+    unsigned short* s_ones = s_xi + K::XI_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kq = lane >> 4;
+    const int pair = wave & 3, role = wave >> 2;                             // weight gradient: role 0 taps 0-4, role 1 taps 5-8 + bias (wave-uniform)
+#ifdef BF_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
+#endif
+    const unsigned short* g_dp = (const unsigned short*)a.in;
+    const unsigned short* g_xi = (const unsigned short*)a.wg_in;
+    unsigned short* g_out = (unsigned short*)a.out;
+
+    for (int e = tid; e < C::COUT * C::WS / 8; e += K::NT) ((uint4*)s_w)[e] = ((const uint4*)a.wbank)[e];
+    for (int e = tid; e < K::IN_ELEMS / 8; e += K::NT) ((uint4*)s_in)[e] = (uint4){0u, 0u, 0u, 0u};            // halo columns stay zero
+    for (int e = tid; e < K::XI_ELEMS / 8; e += K::NT) ((uint4*)s_xi)[e] = (uint4){0u, 0u, 0u, 0u};
+    for (int e = tid; e < K::ONES_ELEMS / 2; e += K::NT) ((unsigned*)s_ones)[e] = 0x3f803f80u;
+
+    // ---- staging registers: 16-byte word e of the pooled stage / of the input tile is contiguous from the item's first row
+    uint4 rd, rxi[K::KXI]; uint2 ra;
+    // A workgroup takes whole images, item k = conv rows 8k .. 8k+7 (work = 4 * local image + k; image = blockIdx.x + local * gridDim.x).
+    // Every load is unconditional from a row clamped into the image; rows outside it are replaced when the registers are stored
+    // (a load under a condition made the compiler wait for it right where it was issued).
+    auto item_loads = [&](int work) {                                         // pooled rows 4k .. 4k+5, input rows ty0-1 .. ty0+8
+        const int img = blockIdx.x + (work >> 2) * gridDim.x, k = work & 3, ty0 = k * 8;
+        const int oy = 4 * k + tid / 64, oyc = oy < 16 ? oy : 15;
+        const long long po = (((long long)img * 16 + oyc) * 16 * 4 + tid % 64) * 8;
+        rd = *(const uint4*)(g_dp + po); ra = *(const uint2*)(a.pool_arg + po);
+#pragma unroll
+        for (int q = 0; q < K::KXI; ++q) {
+            const int e = tid + q * K::NT, gy = ty0 - 1 + e / 64, gyc = gy < 0 ? 0 : (gy > 31 ? 31 : gy);
+            rxi[q] = *(const uint4*)(g_xi + (((long long)img * 32 + gyc) * 64 + e % 64) * 8);
+        }
+    };
+    // ---- weight-gradient state: 10 accumulator tiles (slot s, channel block cb); role 0: slot = tap, role 1: slots 0-3 = taps 5-8, slot 4 = bias
+    f32x4 wacc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) wacc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int cp = lane & 3;
+    // this lane's first source pixel of the pair's first step (tile coordinates); the second half is +8 columns, the second step +1 row
+    const int pl0 = 64 * pair + 16 * (kq >> 1) + 4 * (kq & 1) + ((lane & 15) >> 2);
+    const int prow0 = (pl0 / 32) * C::PW + pl0 % 32;
+    const unsigned short* dv_p = s_in + (prow0 + C::PW + 1) * C::S + 4 * cp;      // d(conv output) at the pixel: s_in row 0 = ty0-1, col 0 = -1
+    const unsigned short* xv_p = s_xi + prow0 * K::SX + 4 * cp;                   // forward input at pixel + tap - (1, 1): same origin
+    // ---- data-gradient constants: two 16-pixel tiles per wave (tile = half a row: both tiles of a wave are in row `wave`)
+    const unsigned short* av_p = s_in + (wave * C::PW + i) * C::S + kq * 8;
+    const unsigned short* bv_p = s_w + i * C::WS + kq * 8;
+    const int ooff = (wave * 32 + i) * 16 + kq * 4;
+    // One code path for both roles (two paths cost a second copy of the accumulators): the role only changes where the five slots
+    // read their forward-input operand; the bias slot of role 1 reads a block of 1.0s, so its "tap" sums d(conv output) itself.
+    const unsigned short* xvp[5];
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+        const int tap = role ? 5 + sl : sl;
+        xvp[sl] = (role && sl == 4) ? s_ones : xv_p + ((tap / 3) * C::PW + tap % 3) * K::SX;
+    }
+    auto wg_steps = [&]() {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 dv[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(dv_p + st * C::PW * C::S + cb * 16));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(dv_p + (st * C::PW + 8) * C::S + cb * 16));
+                dv[cb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int sl = 0; sl < 5; ++sl) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xvp[sl] + st * C::PW * K::SX));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xvp[sl] + (st * C::PW + 8) * K::SX));
+                const bf16x8 xv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) wacc[sl * 2 + cb] = MFMA_BF16(dv[cb], xv, wacc[sl * 2 + cb]);
+            }
+        }
+    };
+
+    const int nwork = 4 * ((a.n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);       // grid <= n: at least one image
+    item_loads(0);
+    B2CK(7);                                                                 // prologue: LDS fills, constants, first loads issued
+    uint2 ost[2] = {(uint2){0u, 0u}, (uint2){0u, 0u}}; unsigned short* ob = g_out;
+    for (int work = 0; work < nwork; ++work) {
+        const int img = blockIdx.x + (work >> 2) * gridDim.x, k = work & 3, ty0 = k * 8;
+        __syncthreads();                                                     // the previous item's LDS reads are done
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): the staged loads, once, on every path (else the compiler waits behind the stores below)
+        B2CK(0);
+        // Rolling gradient rows: s_in row r = conv row ty0-1+r.  Rows 0-2 of this item are rows 8-10 of the previous one (the gather
+        // always runs one block row ahead); the first item of an image has a zero row 0 (conv row -1) and gathers rows 1-2 itself.
+        if (k) { for (int e = tid; e < 3 * K::ROW_WORDS; e += K::NT) ((uint4*)s_in)[e] = ((const uint4*)s_in)[8 * K::ROW_WORDS + e]; }
+        else if (tid < K::ROW_WORDS) ((uint4*)s_in)[tid] = (uint4){0u, 0u, 0u, 0u};
+        if (tid < PS::NW) {
+            const bool in = 4 * k + tid / 64 < 16;                           // pooled rows past the image: zero gradient, arg-max that matches no position
+            *(uint4*)(s_pd + tid * 8) = in ? rd : (uint4){0u, 0u, 0u, 0u};
+            *(uint2*)((uint8_t*)(s_pd + PS::PD_ELEMS) + tid * 8) = in ? ra : (uint2){0xffffffffu, 0xffffffffu};
+        }
+#pragma unroll
+        for (int q = 0; q < K::KXI; ++q) {
+            const int e = tid + q * K::NT, gy = ty0 - 1 + e / 64;
+            if (e < K::NXI) *(uint4*)(s_xi + ((e / 64) * C::PW + (e / 2) % 32 + 1) * K::SX + (e % 2) * 8) = (gy >= 0 && gy < 32) ? rxi[q] : (uint4){0u, 0u, 0u, 0u};
+        }
+        // the previous item's output leaves here, behind the wait for the staged loads: its stores have a whole item to complete
+        // before the next such wait (vmcnt counts loads and stores in order)
+        if (work) { *(uint2*)(ob + ooff) = ost[0]; *(uint2*)(ob + ooff + 256) = ost[1]; }
+        __syncthreads();
+        B2CK(1);
+        // block rows 4k+1 .. 4k+4 (first item: 4k .. 4k+4) -> conv rows up to 8k+9, every one of them stored (s_in row = 2 * bl + dy + 1)
+#pragma unroll 1
+        for (int task = tid + (k ? 256 : 0); task < PS::NTASK2; task += K::NT) PS::gather_task2(s_pd, task, 4 * k, -1000, 1000, s_in, ty0 - 1, C::PW, 1, C::S);
+        item_loads(work + 1 < nwork ? work + 1 : work);                     // unconditional (the last item is simply fetched again): no merge, no copies behind the loads
+        B2CK(2);
+        __syncthreads();
+        B2CK(3);
+        // ---- weight gradient: the pair's two pixel steps, this role's five slots
+        wg_steps();
+        B2CK(4);
+        // ---- data gradient of the wave's two pixel tiles
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {
+            const bf16x8 bv = *(const bf16x8*)(bv_p + m * 32);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[mt] = MFMA_BF16(bv, *(const bf16x8*)(av_p + ((m / 3) * C::PW + (m % 3) + 16 * mt) * C::S), acc[mt]);
+        }
+        B2CK(5);
+        ob = g_out + ((long long)img * 32 + ty0) * 32 * 16;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ost[mt] = (uint2){mi_pk_bf16(acc[mt][0], acc[mt][1]), mi_pk_bf16(acc[mt][2], acc[mt][3])};
+    }
+    if (nwork > 0) { *(uint2*)(ob + ooff) = ost[0]; *(uint2*)(ob + ooff + 256) = ost[1]; }
+    // ---- waves summed through LDS in fixed order (role 0: waves 0-3 over taps 0-4; role 1: waves 4-7 over taps 5-8 and the bias sums)
+    __syncthreads();
+    float* red = (float*)smem_h;
+    float* redb = red + K::WLEN;
+    for (int w = 0; w < 4; ++w) {
+        if (pair == w) {
+#pragma unroll
+            for (int sl = 0; sl < 5; ++sl)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = wacc[sl * 2 + cb][r];
+                        if (role && sl == 4) { if (i == 0) { const int o = cb * 16 + kq * 4 + r; redb[o] = (w == 0) ? v : redb[o] + v; } }
+                        else {
+                            const int tap = role ? 5 + sl : sl;
+                            const int o = ((cb * 16 + kq * 4 + r) * 9 + tap) * 16 + i;
+                            red[o] = (w == 0) ? v : red[o] + v;
+                        }
+                    }
+        }
+        __syncthreads();
+    }
+    float* slab = a.wg_partial + (long long)blockIdx.x * K::SLAB;
+    for (int e = tid; e < K::SLAB; e += K::NT) slab[e] = red[e];           // the bias sums follow the weights in both layouts
+#ifdef BF_TIMING
+    B2CK(6);                                                                 // last output stores, wave reduction, slab
+    if ((threadIdx.x & 255) == 0) for (int q = 0; q < 8; ++q) atomicAdd(&g_bf_timing[(threadIdx.x >> 8) * 8 + q], (unsigned long long)tacc_[q]);
+#endif
+}
+static int b2bwd_grid(int n) { return n > 512 ? 512 : n; }      // whole images per workgroup, two workgroups per CU
+static void launch_block2_conv_bwd(const ConvArgs& a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)block2_conv_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2Bwd::LDS); attr = true; }
+    const int grid = b2bwd_grid(a.n);
+    if (grid < 1) return;
+    hipLaunchKernelGGL(block2_conv_bwd_bf16_kernel, dim3(grid), dim3(B2Bwd::NT), B2Bwd::LDS, st, a);
 }
 
 // ------------------------------------------------------------------------------------------ filter-bank packing
@@ -1243,7 +1518,7 @@ void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
 void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
     switch (s) {
         case CS_16_16_32: launch_bf_t<BD_16_16_32>(a, st); break;
-        case CS_16_32_32: if (a.pool_arg && a.wg_partial) launch_bf_t<BD_16_32_32, true, true>(a, st);
+        case CS_16_32_32: if (a.pool_arg && a.wg_partial) { if (B2BWD_NEW) launch_block2_conv_bwd(a, st); else launch_bf_t<BD_16_32_32, true, true>(a, st); }
                           else if (a.pool_arg) launch_bf_t<BD_16_32_32, true>(a, st); else launch_bf_t<BD_16_32_32>(a, st); break;
         case CS_32_32_16: if (a.pool_arg) launch_bf_t<BD_32_32_16, true>(a, st); else launch_bf_t<BD_32_32_16>(a, st); break;
         case CS_32_32_8:  launch_bf_t<BD_32_32_8>(a, st); break;
@@ -1251,4 +1526,4 @@ void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
     }
 }
 
-int conv_bwd_fused_grid(ConvShape s, int n) { return s == CS_16_32_32 ? bf_grid<BD_16_32_32, true, true>(n) : -1; }
+int conv_bwd_fused_grid(ConvShape s, int n) { return s == CS_16_32_32 ? (B2BWD_NEW ? b2bwd_grid(n) : bf_grid<BD_16_32_32, true, true>(n)) : -1; }

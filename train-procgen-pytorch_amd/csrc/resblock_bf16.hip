@@ -697,14 +697,14 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
 // block) column as in the column-split stand-alone kernel: every wave walks all 4 pixel steps with its 2-3 columns of both
 // layers and owns its slab entries outright (no cross-wave reduction).  (A 256-thread variant with the banks streamed from
 // L2 instead of LDS measured 410 us per launch: every K step waited ~0.5 us for its filter fragment.)
-template <int HW_, int NT_>
+template <int HW_, int NT_, int TH_ = 8>
 struct RbFull32T {                               // HW 16: 8-row tiles, 512 threads; HW 8: whole image, 256 threads (79 KB: two per CU)
-    static constexpr int C = 32, HW = HW_, TH = 8, S = 48, P = HW + 2, TPI = HW / TH, NT = NT_, NW = NT_ / 64;
+    static constexpr int C = 32, HW = HW_, TH = TH_, S = 48, P = HW + 2, TPI = HW / TH, NT = NT_, NW = NT_ / 64;
     static constexpr int XR = TH + 4, YR = TH + 2;
     static constexpr int X_ELEMS = XR * P * S, Y_ELEMS = YR * P * S;
     static constexpr int NK = 9, WS = NK * 32 + 16, W_ELEMS = C * WS;
     static constexpr int NMT1 = YR * HW / 16, NMT2 = TH * HW / 16;                                            // HW 16: 10 / 8 tiles over 8 waves; HW 8: 5 / 4 over 4 waves
-    static_assert(NMT2 == NW && NMT1 <= 2 * NW, "one conv2 tile and at most two conv1 tiles per wave");
+    static_assert(TH != 8 || (NMT2 == NW && NMT1 <= 2 * NW), "one conv2 tile and at most two conv1 tiles per wave");
     static constexpr int NX = XR * HW * 4, NA = YR * HW * 4;                                                  // 16-byte words staged per tensor
     static constexpr int KX = (NX + NT - 1) / NT, KA = (NA + NT - 1) / NT;
     static constexpr int NSTEP = TH * HW / 32;                                                                 // 4 pixel steps of 32
@@ -713,6 +713,10 @@ struct RbFull32T {                               // HW 16: 8-row tiles, 512 thre
     static constexpr size_t LDS_BYTES = (size_t)(X_ELEMS + 3 * Y_ELEMS + 2 * W_ELEMS) * 2;
 };
 using RbFull32 = RbFull32T<16, 512>;
+#ifndef RB32S_TH
+#define RB32S_TH 8           // rows per item of the wave-specialised kernel (16 = whole image: 128 KB of LDS now that no bank sits there)
+#endif
+using RbFull32W = RbFull32T<16, 512, RB32S_TH>;
 using RbFull32S = RbFull32T<8, 256>;
 
 template <class C>
@@ -936,7 +940,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full32s_bf16_kernel(RbFul
     // waves may keep live: two separate sets spilled 471 registers).  conv role: st[2m + nb] = B fragment (tap m, output block nb) of
     // conv2's transposed bank, st[18 + 2m + nb] of conv1's.  weight-gradient role: st[2qq + cb] / st[10 + 2qq + cb] = accumulator
     // tiles of conv2 / conv1 for this wave's column qq and output block cb, st[20 + cb] = bias accumulators (rw 2: conv2, rw 3: conv1).
-    f32x4 st[36];
+    constexpr int NT2 = 256, KX2 = (C::NX + NT2 - 1) / NT2, KA2 = (C::NA + NT2 - 1) / NT2;
+    constexpr int NST = (22 + KX2 + 2 * KA2) > 36 ? (22 + KX2 + 2 * KA2) : 36;      // 36 fragments (conv role) / 22 accumulators + the prefetch words
+    f32x4 st[NST];
     constexpr int QM = 5;
     const int qcnt = (C::NQ - rw + 3) / 4;                // columns q = rw + 4 * qq of the 18 (tap, input block) columns: 5, 5, 4, 4
     if (conv_role) {
@@ -949,7 +955,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full32s_bf16_kernel(RbFul
             }
     } else {
 #pragma unroll
-        for (int q = 0; q < 36; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};      // accumulators (0 .. 21); 22 .. 30 are the prefetch words
+        for (int q = 0; q < NST; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};     // accumulators (0 .. 21); 22 .. are the prefetch words
     }
     // Drain the 36 fragment loads HERE.  Otherwise the compiler, which sees one register array, guards every first touch of st[k] inside
     // the loop with a counted s_waitcnt vmcnt(35 - k): harmless for the conv waves, but the weight-gradient waves have their nine
@@ -961,8 +967,6 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full32s_bf16_kernel(RbFul
     const int nwork = a.n * C::TPI;
     // Staging (global -> registers one item ahead -> LDS) is the weight-gradient waves' job: their half of st has room for the nine
     // prefetch words (st[22 .. 30]), the conv waves' half is full of filter fragments.  t2 = thread index among those 256 threads.
-    constexpr int NT2 = 256, KX2 = (C::NX + NT2 - 1) / NT2, KA2 = (C::NA + NT2 - 1) / NT2;
-    static_assert(22 + KX2 + 2 * KA2 <= 36, "prefetch words fit the state array");
     const int t2 = tid - 256;
     auto load = [&](int work) {
         const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
@@ -1156,7 +1160,11 @@ static int rb_full32_grid_t(int n) {
     const int w = n * C::TPI;
     return w > 256 * bpc ? 256 * bpc : w;
 }
-int resblock_bwd_full32_grid(ConvShape s, int n) { return s == CS_32_32_16 ? rb_full32_grid_t<RbFull32>(n) : s == CS_32_32_8 ? rb_full32_grid_t<RbFull32S>(n) : -1; }
+#ifndef RB32_SPECIALISED
+#define RB32_SPECIALISED 1
+#endif
+static int rb_full32s_grid(int n);
+int resblock_bwd_full32_grid(ConvShape s, int n) { return s == CS_32_32_16 ? (RB32_SPECIALISED ? rb_full32s_grid(n) : rb_full32_grid_t<RbFull32>(n)) : s == CS_32_32_8 ? rb_full32_grid_t<RbFull32S>(n) : -1; }
 template <class C>
 static void launch_rb_full32_t(const RbFullArgs& a, hipStream_t st) {
     static bool attr = false;
@@ -1168,12 +1176,13 @@ static void launch_rb_full32_t(const RbFullArgs& a, hipStream_t st) {
 #ifndef RB32_SPECIALISED
 #define RB32_SPECIALISED 1
 #endif
+static int rb_full32s_grid(int n) { const int w = n * RbFull32W::TPI; return w > 256 ? 256 : w; }      // one 512-thread workgroup per CU
 static void launch_rb_full32s(const RbFullArgs& a, hipStream_t st) {
-    using C = RbFull32;
+    using C = RbFull32W;
     constexpr size_t LDS = (size_t)(C::X_ELEMS + 3 * C::Y_ELEMS) * 2;          // no bank copies in LDS
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)resblock_bwd_full32s_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
-    const int grid = rb_full32_grid_t<C>(a.n);                                  // same grid = same slab count as the plain kernel
+    const int grid = rb_full32s_grid(a.n);
     if (grid < 1) return;
     hipLaunchKernelGGL(resblock_bwd_full32s_bf16_kernel<C>, dim3(grid), dim3(512), LDS, st, a);
 }
