@@ -27,12 +27,15 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     WgradArgs a{}; a.in = in; a.dout = dout; a.partial = slabs; a.n = n; a.relu_in = 1; a.bf16 = 1;
     ConvArgs c{}; c.in = frames; c.w = w; c.bias = bias; c.n = n; c.bf16 = 1; c.lut16 = lut;
+    int32_t* idx; hipMalloc(&idx, (size_t)n * 4);
+    { std::vector<int32_t> hi(n); for (int k = 0; k < n; ++k) hi[k] = (int)(((long long)k * 4099) % n); hipMemcpy(idx, hi.data(), (size_t)n * 4, hipMemcpyHostToDevice); }
+    if (argc > 3) c.idx = idx;                        // any third argument: frames gathered through an index list, as a minibatch does
     int grid = 0;
     auto run = [&]() {
         if (!strcmp(kn, "w16")) { launch_conv_wgrad_bf16(CS_32_32_16, a, st); grid = wgrad_grid_bf16(CS_32_32_16, n); }
         else if (!strcmp(kn, "w8")) { launch_conv_wgrad_bf16(CS_32_32_8, a, st); grid = wgrad_grid_bf16(CS_32_32_8, n); }
         else if (!strcmp(kn, "c1f")) { launch_conv1_pool_fwd_bf16(c, lut, in, arg, st); grid = n * 8 > 1024 ? 1024 : n * 8; }
-        else { WgradArgs b = a; b.in = frames; b.lut16 = lut; b.pool_arg = arg; launch_conv1_wgrad_bf16(b, lut, st); grid = c1_grid(n); }
+        else { WgradArgs b = a; b.in = frames; b.lut16 = lut; b.pool_arg = arg; if (argc > 3) b.idx = idx; launch_conv1_wgrad_bf16(b, lut, st); grid = c1_grid(n); }
     };
     run(); hipStreamSynchronize(st);
 #ifdef WG_TIMING

@@ -1096,29 +1096,44 @@ struct C1T {
 };
 using C1 = C1T<8>;          // forward tile
 using C1W = C1T<4>;         // weight-gradient tile (smaller LDS footprint -> 4 workgroups per CU)
+// The frame index of a minibatch sample is a load of its own (idx[img]) in front of the pixel loads: it is resolved one item
+// earlier than the pixels (c1_frame for item k+2 is issued with the pixel loads of item k+1), and the pixel loads are unconditional
+// from a row clamped into the image -- c1_store zeroes the rows outside it.  (A conditional load made the compiler wait for it where
+// it was issued, and the dependent pair exposed a full memory round trip per item.)
+__device__ __forceinline__ long long c1_frame(const int32_t* idx, long long in_base, int img) { return idx ? (long long)idx[img] : in_base + img; }
+// The early fetch goes through the constant address space with a uniform address, i.e. a scalar load (lgkmcnt): kept out of the
+// in-order vmcnt stream of the pixel loads, where -- being the youngest load and needed first -- it forced the older pixel loads to
+// be drained.  With idx == null a word of the frames is fetched and ignored (one path: no merge of load histories).
+typedef const __attribute__((address_space(4))) int32_t* c1_const_i32p;
+__device__ __forceinline__ int c1_frame_fetch(const int32_t* idx, const void* any_valid, int img) {
+    const int32_t* p = idx ? idx + img : (const int32_t*)any_valid;
+    return *(c1_const_i32p)p;
+}
+__device__ __forceinline__ long long c1_frame_of(const int32_t* idx, long long in_base, int fetched, int img) {
+    return idx ? (long long)fetched : in_base + img;
+}
 template <class C1>
-__device__ __forceinline__ void c1_load(uint32_t (&r)[C1::NLD], const uint8_t* frames, const int32_t* idx, long long in_base, int img, int ty0) {
-    const int e = threadIdx.x, row = e >> 4, g = e & 15, gy = ty0 + row - 1;
-    r[0] = r[1] = r[2] = 0u;
-    if (e < C1::NTASK && gy >= 0 && gy < C1::HW) {
-        const long long frame = idx ? (long long)idx[img] : in_base + img;
-        const uint32_t* p = (const uint32_t*)(frames + frame * (C1::HW * C1::HW * 3) + gy * (C1::HW * 3) + g * 12);
-        r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
-    }
+__device__ __forceinline__ void c1_load(uint32_t (&r)[C1::NLD], const uint8_t* frames, long long frame, int ty0) {
+    // every thread loads (no branch: the compiler's in-order vmcnt bookkeeping stays exact); threads past the tile repeat its last row
+    const int e = threadIdx.x, row = (e >> 4) < C1::PH ? (e >> 4) : C1::PH - 1, g = e & 15, gy = ty0 + row - 1;
+    const int gyc = gy < 0 ? 0 : (gy > C1::HW - 1 ? C1::HW - 1 : gy);
+    const uint32_t* p = (const uint32_t*)(frames + frame * (C1::HW * C1::HW * 3) + gyc * (C1::HW * 3) + g * 12);
+    r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
 }
 // uint8 -> bf16(k/255): k * (1/255) rounded to bf16 equals the bf16 of the exact quotient for all 256 values (checked
 // exhaustively on the host, tests/test_host_logic.py), so no table: 12 converts + 4 8-byte LDS stores per task.
-template <class C1>
-__device__ __forceinline__ void c1_store(const uint32_t (&r)[C1::NLD], unsigned short* s_in, const unsigned short*) {
-    const int e = threadIdx.x, row = e >> 4, g = e & 15;
+template <class C1, bool ONE4 = false>      // ONE4: the padding channel holds 1.0 (weight gradient: its centre-tap column sums the bias gradient)
+__device__ __forceinline__ void c1_store(const uint32_t (&r)[C1::NLD], unsigned short* s_in, int ty0) {
+    const int e = threadIdx.x, row = e >> 4, g = e & 15, gy = ty0 + row - 1;
     if (e < C1::NTASK) {
+        const bool in = gy >= 0 && gy < C1::HW;
         float f[12];
 #pragma unroll
-        for (int b = 0; b < 12; ++b) f[b] = (float)((r[b >> 2] >> (8 * (b & 3))) & 0xffu) * (1.0f / 255.0f);
+        for (int b = 0; b < 12; ++b) f[b] = in ? (float)((r[b >> 2] >> (8 * (b & 3))) & 0xffu) * (1.0f / 255.0f) : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *(uint2*)(s_in + (row * C1::PW + 1 + g * 4 + j) * 4) =
-                (uint2){mi_pk_bf16(f[3 * j], f[3 * j + 1]), mi_pk_bf16(f[3 * j + 2], 0.f)};
+                (uint2){mi_pk_bf16(f[3 * j], f[3 * j + 1]), mi_pk_bf16(f[3 * j + 2], ONE4 ? 1.f : 0.f)};
     }
 }
 
@@ -1139,13 +1154,19 @@ __global__ __launch_bounds__(256) void conv1_fwd_bf16_kernel(ConvArgs a, const u
     constexpr int off8 = (2 * C1::PW + 2) * 4;
     const int nwork = a.n * C1::TPI;
     uint32_t regs[C1::NLD];
-    if ((int)blockIdx.x < nwork) c1_load<C1>(regs, (const uint8_t*)a.in, a.idx, a.in_base, blockIdx.x / C1::TPI, (blockIdx.x % C1::TPI) * C1::TH);
+    auto item = [&](int w) { return w < nwork ? w : nwork - 1; };          // past the end: the last item again (loads stay unconditional)
+    int frame_next = 0;
+    if ((int)blockIdx.x < nwork) {
+        c1_load<C1>(regs, (const uint8_t*)a.in, c1_frame(a.idx, a.in_base, blockIdx.x / C1::TPI), (blockIdx.x % C1::TPI) * C1::TH);
+        frame_next = c1_frame_fetch(a.idx, a.in, item(blockIdx.x + gridDim.x) / C1::TPI);
+    }
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         const int img = work / C1::TPI, ty0 = (work % C1::TPI) * C1::TH;
         __syncthreads();
-        c1_store<C1>(regs, s_in, lut16);
+        c1_store<C1>(regs, s_in, ty0);
         __syncthreads();
-        if (work + (int)gridDim.x < nwork) { const int w2 = work + gridDim.x; c1_load<C1>(regs, (const uint8_t*)a.in, a.idx, a.in_base, w2 / C1::TPI, (w2 % C1::TPI) * C1::TH); }
+        { const int w2 = item(work + gridDim.x); c1_load<C1>(regs, (const uint8_t*)a.in, c1_frame_of(a.idx, a.in_base, frame_next, w2 / C1::TPI), (w2 % C1::TPI) * C1::TH);
+          frame_next = c1_frame_fetch(a.idx, a.in, item(work + 2 * gridDim.x) / C1::TPI); }
         const bf16x8 bw1 = *(const bf16x8*)(s_w + i * C1_WS + kq * 8);
         const bf16x8 bw2 = *(const bf16x8*)(s_w + i * C1_WS + 32 + kq * 8);
 #pragma unroll
@@ -1215,17 +1236,23 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
     constexpr int off8 = (2 * C1P::PW + 2) * 4;
     const int nwork = a.n * 8;                             // 8 groups of 4 pooled rows per image
     uint32_t regs[C1P::NLD];
-    if ((int)blockIdx.x < nwork) c1_load<C1P>(regs, (const uint8_t*)a.in, a.idx, a.in_base, blockIdx.x / 8, (blockIdx.x % 8) * 8 - 1);
+    auto item = [&](int w) { return w < nwork ? w : nwork - 1; };          // past the end: the last item again (loads stay unconditional)
+    int frame_next = 0;
+    if ((int)blockIdx.x < nwork) {
+        c1_load<C1P>(regs, (const uint8_t*)a.in, c1_frame(a.idx, a.in_base, blockIdx.x / 8), (blockIdx.x % 8) * 8 - 1);
+        frame_next = c1_frame_fetch(a.idx, a.in, item(blockIdx.x + gridDim.x) / 8);
+    }
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         const int img = work / 8, oy0 = (work % 8) * 4, cy0 = 2 * oy0 - 1;      // first conv row of this item (may be -1)
         TCK(0);
         __syncthreads();
         TCK(1);
-        c1_store<C1P>(regs, s_in, lut16);
+        c1_store<C1P>(regs, s_in, cy0);
         TCK(2);
         __syncthreads();
         TCK(3);
-        if (work + (int)gridDim.x < nwork) { const int w2 = work + gridDim.x; c1_load<C1P>(regs, (const uint8_t*)a.in, a.idx, a.in_base, w2 / 8, (w2 % 8) * 8 - 1); }
+        { const int w2 = item(work + gridDim.x); c1_load<C1P>(regs, (const uint8_t*)a.in, c1_frame_of(a.idx, a.in_base, frame_next, w2 / 8), (w2 % 8) * 8 - 1);
+          frame_next = c1_frame_fetch(a.idx, a.in, item(work + 2 * gridDim.x) / 8); }
         TCK(4);
         const bf16x8 bw1 = *(const bf16x8*)(s_w + i * C1_WS + kq * 8);
         const bf16x8 bw2 = *(const bf16x8*)(s_w + i * C1_WS + 32 + kq * 8);
@@ -1288,16 +1315,14 @@ void launch_conv1_pool_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, 
     hipLaunchKernelGGL(conv1_pool_fwd_bf16_kernel, dim3(grid), dim3(256), 0, st, a, lut16, (unsigned short*)p_out, p_arg);
 }
 
-constexpr int C1_SI = 48;          // im2col row stride (bf16 elements): 16 x odd -> conflict-free transpose reads
 // POOLED: a.dout is the gradient of the POOLED map (32x32x16) and a.pool_arg its arg-max bytes; the conv-output
 // gradient tile is rebuilt in LDS from the 3 pooled rows that touch the 4 conv rows of the item (max-pool backward
 // fused into the staging: no 64x64x16 gradient tensor in HBM).
 template <bool POOLED>
 __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, const unsigned short* lut16) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
-    unsigned short* s_in = smem_h;                                   // [396][4]
-    unsigned short* s_col = smem_h + ((C1W::NPIX * 4 + 7) / 8) * 8;   // [256][48] (27 real columns)
-    unsigned short* s_do = s_col + C1W::NT * C1_SI;                   // [256][16]
+    unsigned short* s_in = smem_h;                                   // [396][4]: 3 channels + 1.0
+    unsigned short* s_do = smem_h + ((C1W::NPIX * 4 + 7) / 8) * 8;    // [256][16]
     unsigned short* s_pd = s_do + C1W::NT * 16;                       // POOLED: [3][32][16] pooled gradient
     uint8_t* s_pa = (uint8_t*)(s_pd + 3 * 32 * 16);                   // POOLED: [3][32][16] arg-max bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
@@ -1305,50 +1330,59 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
 #ifdef WG_TIMING
     long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
 #endif
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int e = tid; e < C1W::NPIX * 4; e += 256) s_in[e] = 0;
     const int nwork = a.n * C1W::TPI;
-    uint32_t regs[C1W::NLD];
+    // Two staging register sets: the loads of item k+2 are issued while item k is processed.  One item lasts ~2.5 us, about one
+    // loaded-HBM round trip, so with a single set every item waited for its own data (phases "store" + "issue" = 33 % of the clocks).
     constexpr int NDO = C1W::NT * 2 / 256;                            // NT px x 2 chunks of 8 channels
-    uint4 rdo[NDO];
-    uint2 rpa = {0u, 0u};
-    auto load_do = [&](int img, int ty0) {
-        if (POOLED) {                                               // 3 pooled rows x 32 x 2 halves = 192 (uint4, uint2) pairs
-            rdo[0] = (uint4){0u, 0u, 0u, 0u}; rpa = (uint2){0xffffffffu, 0xffffffffu};
-            const int pr = tid >> 6, oy = ty0 / 2 + pr;
-            if (tid < 192 && oy < 32) {
-                const size_t o = (((size_t)img * 32 + oy) * 32) * 16 + (size_t)(tid & 63) * 8;
-                rdo[0] = *(const uint4*)(g_do + o);
-                rpa = *(const uint2*)(a.pool_arg + o);
-            }
+    struct Stage { uint32_t regs[C1W::NLD]; uint4 rdo[NDO]; uint2 rpa; };
+    Stage S0, S1;
+    auto load_do = [&](Stage& S, int img, int ty0) {
+        if (POOLED) {                                               // 3 pooled rows x 32 x 2 halves = 192 (uint4, uint2) pairs; unconditional,
+            const int pr = tid >> 6, oy = ty0 / 2 + (pr < 2 ? pr : 2);   // clamped: rows past the map are replaced when the registers are stored
+            const size_t o = (((size_t)img * 32 + (oy < 32 ? oy : 31)) * 32) * 16 + (size_t)(tid & 63) * 8;
+            S.rdo[0] = *(const uint4*)(g_do + o);
+            S.rpa = *(const uint2*)(a.pool_arg + o);
         } else {
 #pragma unroll
             for (int k = 0; k < NDO; ++k) {
                 const int e = tid + k * 256, pl = e >> 1, c8 = e & 1;
-                rdo[k] = *(const uint4*)(g_do + (((long long)img * C1W::HW + ty0 + pl / C1W::TW) * C1W::HW + pl % C1W::TW) * 16 + c8 * 8);
+                S.rdo[k] = *(const uint4*)(g_do + (((long long)img * C1W::HW + ty0 + pl / C1W::TW) * C1W::HW + pl % C1W::TW) * 16 + c8 * 8);
             }
         }
     };
-    if ((int)blockIdx.x < nwork) {
-        const int img = blockIdx.x / C1W::TPI, ty0 = (blockIdx.x % C1W::TPI) * C1W::TH;
-        c1_load<C1W>(regs, (const uint8_t*)a.in, a.idx, a.in_base, img, ty0); load_do(img, ty0);
+    auto item = [&](int w) { return w < nwork ? w : nwork - 1; };          // past the end: the last item again (loads stay unconditional)
+    const int G = gridDim.x;
+    int frame_next = 0;                                                     // fetched index of item (current + 2G), see c1_frame_fetch
+    {
+        const int w0 = blockIdx.x, w1 = item(w0 + G);
+        c1_load<C1W>(S0.regs, (const uint8_t*)a.in, c1_frame(a.idx, a.in_base, w0 / C1W::TPI), (w0 % C1W::TPI) * C1W::TH); load_do(S0, w0 / C1W::TPI, (w0 % C1W::TPI) * C1W::TH);
+        c1_load<C1W>(S1.regs, (const uint8_t*)a.in, c1_frame(a.idx, a.in_base, w1 / C1W::TPI), (w1 % C1W::TPI) * C1W::TH); load_do(S1, w1 / C1W::TPI, (w1 % C1W::TPI) * C1W::TH);
+        frame_next = c1_frame_fetch(a.idx, a.in, item(w0 + 2 * G) / C1W::TPI);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the prologue's index fetch is the youngest load: drain once here, not in the loop
     }
-    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+    auto step = [&](int work, Stage& S) {
         TCK(0);
         __syncthreads();
         TCK(1);
-        c1_store<C1W>(regs, s_in, lut16);
+        c1_store<C1W, true>(S.regs, s_in, (work % C1W::TPI) * C1W::TH);
         if (POOLED) {
-            if (tid < 192) { *(uint4*)(s_pd + tid * 8) = rdo[0]; *(uint2*)(s_pa + tid * 8) = rpa; }
+            if (tid < 192) {
+                const bool in = (work % C1W::TPI) * C1W::TH / 2 + (tid >> 6) < 32;      // the third pooled row of an image's last item does not exist
+                *(uint4*)(s_pd + tid * 8) = in ? S.rdo[0] : (uint4){0u, 0u, 0u, 0u}; *(uint2*)(s_pa + tid * 8) = in ? S.rpa : (uint2){0xffffffffu, 0xffffffffu};
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < NDO; ++k) { const int e = tid + k * 256; *(uint4*)(s_do + (e >> 1) * 16 + (e & 1) * 8) = rdo[k]; }
+            for (int k = 0; k < NDO; ++k) { const int e = tid + k * 256; *(uint4*)(s_do + (e >> 1) * 16 + (e & 1) * 8) = S.rdo[k]; }
         }
         TCK(2);
         __syncthreads();
-        if (work + (int)gridDim.x < nwork) {
-            const int w2 = work + gridDim.x, img = w2 / C1W::TPI, ty0 = (w2 % C1W::TPI) * C1W::TH;
-            c1_load<C1W>(regs, (const uint8_t*)a.in, a.idx, a.in_base, img, ty0); load_do(img, ty0);
+        {
+            const int w2 = item(work + 2 * G), img = w2 / C1W::TPI, ty0 = (w2 % C1W::TPI) * C1W::TH;
+            const long long frame = c1_frame_of(a.idx, a.in_base, frame_next, img);
+            frame_next = c1_frame_fetch(a.idx, a.in, item(work + 3 * G) / C1W::TPI);       // ahead of the pixel loads: vmcnt retires in order, and the
+            c1_load<C1W>(S.regs, (const uint8_t*)a.in, frame, ty0); load_do(S, img, ty0);   // next step needs this index but not these pixels
         }
         TCK(3);
         if (POOLED) {       // max-pool backward into the LDS tile.  A thread owns a 2x2 block of conv pixels x 4 channels: the
@@ -1392,27 +1426,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
                 }
         }
         TCK(4);
-        // im2col: pixel p -> its 27 (tap, ci) values, contiguous (columns 27..31 zero)
-#pragma unroll
-        for (int h = 0; h < C1W::NT / 256; ++h) {
-            const int pl = tid + h * 256, y = pl / C1W::TW, x = pl % C1W::TW;
-            unsigned short v[32];
-#pragma unroll
-            for (int k = 27; k < 32; ++k) v[k] = 0;
-            v[27] = 0x3f80;                                           // column 27 = 1.0: its output column is the bias gradient
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const uint2 t = *(const uint2*)(s_in + ((y + tap / 3) * C1W::PW + x + tap % 3) * 4);
-                v[tap * 3] = (unsigned short)(t.x & 0xffffu); v[tap * 3 + 1] = (unsigned short)(t.x >> 16); v[tap * 3 + 2] = (unsigned short)(t.y & 0xffffu);
-            }
-            uint4* d = (uint4*)(s_col + pl * C1_SI);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                d[k] = (uint4){(unsigned)v[8 * k] | ((unsigned)v[8 * k + 1] << 16), (unsigned)v[8 * k + 2] | ((unsigned)v[8 * k + 3] << 16),
-                               (unsigned)v[8 * k + 4] | ((unsigned)v[8 * k + 5] << 16), (unsigned)v[8 * k + 6] | ((unsigned)v[8 * k + 7] << 16)};
-        }
         TCK(5);
         __syncthreads();
+        // B operand straight from the staged tile: the 16 columns of an MFMA are 4 taps x (3 channels + the 1.0), column group cp of
+        // MFMA m reading pixel + tap(4m + cp) -- no im2col copy.  Three MFMAs cover the 9 taps (the last one's groups 1-3 repeat tap 8).
         for (int t = wave; t < C1W::NT / 32; t += 4) {
             int row[2];
 #pragma unroll
@@ -1420,15 +1437,22 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
             const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + row[0] * 16 + 4 * cp));
             const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_do + row[1] * 16 + 4 * cp));
             const bf16x8 av = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+            int prow[2];
 #pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_col + row[0] * C1_SI + ib * 16 + 4 * cp));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_col + row[1] * C1_SI + ib * 16 + 4 * cp));
-                acc[ib] = MFMA_BF16(av, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), acc[ib]);
+            for (int h = 0; h < 2; ++h) prow[h] = (row[h] / C1W::TW) * C1W::PW + row[h] % C1W::TW;      // tile coordinates: tap (0, 0) = this cell
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int tap = (4 * m + cp) < 9 ? 4 * m + cp : 8, toff = (tap / 3) * C1W::PW + tap % 3;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_in + (prow[0] + toff) * 4));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_in + (prow[1] + toff) * 4));
+                acc[m] = MFMA_BF16(av, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), acc[m]);
             }
         }
         TCK(6);
-    }
+    };
+    int work = blockIdx.x;
+    for (; work + G < nwork; work += 2 * G) { step(work, S0); step(work + G, S1); }      // (a conditional second step would merge two load histories:
+    if (work < nwork) step(work, S0);                                                   //  the compiler then drains vmcnt to 0 at every wait)
 #ifdef WG_TIMING
     if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_wg_timing[k], (unsigned long long)tacc_[k]);
 #endif
@@ -1437,11 +1461,14 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
+            for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int jj = ib * 16 + i;
-                    if (jj <= 27) { const int o = (jj < 27) ? (kq * 4 + r) * 27 + jj : 432 + kq * 4 + r; red[o] = (w == 0) ? acc[ib][r] : red[o] + acc[ib][r]; }
+                for (int r = 0; r < 4; ++r) {          // column i of MFMA m = (tap 4m + i/4, channel i%4); channel 3 of the centre tap = bias sum
+                    const int tap = 4 * m + (i >> 2), ci = i & 3;
+                    if (tap < 9 && (ci < 3 || tap == 4)) {
+                        const int o = (ci < 3) ? (kq * 4 + r) * 27 + tap * 3 + ci : 432 + kq * 4 + r;
+                        red[o] = (w == 0) ? acc[m][r] : red[o] + acc[m][r];
+                    }
                 }
         }
         __syncthreads();
@@ -1449,7 +1476,11 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
     float* slab = a.partial + (long long)blockIdx.x * 448;
     for (int e = tid; e < 448; e += 256) slab[e] = red[e];
 }
-constexpr size_t C1_WG_LDS = (size_t)(((C1W::NPIX * 4 + 7) / 8) * 8 + C1W::NT * C1_SI + C1W::NT * 16) * 2;
+#ifndef C1_WG_PAD
+#define C1_WG_PAD (36 * 1024)      // requested LDS: at most 4 workgroups of the 1024 land on one CU (an even spread; the tiles need 12-16 KB)
+#endif
+constexpr size_t C1_WG_TILES = (size_t)(((C1W::NPIX * 4 + 7) / 8) * 8 + C1W::NT * 16) * 2;
+constexpr size_t C1_WG_LDS = C1_WG_TILES + 3 * 32 * 16 * 3 > C1_WG_PAD ? C1_WG_TILES : C1_WG_PAD - 3 * 32 * 16 * 3;
 constexpr size_t C1_WGP_LDS = C1_WG_LDS + 3 * 32 * 16 * 3;
 static int c1_grid(int n) { const int w = n * C1W::TPI; return w > 1024 ? 1024 : w; }
 void launch_conv1_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, hipStream_t st) {
