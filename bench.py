@@ -269,7 +269,19 @@ def main():
             for h in hg:
                 h[...] = rng.integers(0, 256, size=h.shape, dtype=np.uint8)
 
-    phase = {"rollout_s": 0.0}
+    phase = {"rollout_s": 0.0, "update_enqueue_s": 0.0}
+    # host time inside the update's enqueueing calls (no sync in them): next to the update phase's wall time it says whether a box's
+    # host kept the GPU fed (a loaded host shows up here, not in the per-kernel times)
+    def _timed(fn):
+        def w(*a, **k):
+            t = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                phase["update_enqueue_s"] += time.perf_counter() - t
+        return w
+    eng.minibatch = _timed(eng.minibatch)
+    agent.optimizer.step = _timed(agent.optimizer.step)
 
     def iteration(it):
         t_r = time.perf_counter()
@@ -301,7 +313,7 @@ def main():
     eng.profile_enable(0 if args.no_kernel_profile else ((2 if args.profile_rollout else 1) | (max(1, args.profile_period) << 8)))
     eng.profile_read(reset=True)
     fence()
-    phase["rollout_s"] = 0.0
+    phase["rollout_s"] = 0.0; phase["update_enqueue_s"] = 0.0
     t0 = time.perf_counter()
     for it in range(args.steps):
         summary = iteration(args.warmup + it)
@@ -355,7 +367,8 @@ def main():
                    "B_step_MB": b_step / 1e6, "F_step_MFLOP": f_step / 1e6, "hbm_frac": per_gpu * b_step / (HBM_PEAK_GBS * 1e9),
                    "mfma_frac": per_gpu * f_step / (mpeak * 1e12)})(value / world, 8.99e6 if args.precision == "bf16" else 17.90e6, 601.78e6,
                                                                    MFMA_BF16_PEAK_TF if args.precision == "bf16" else MFMA_F32_PEAK_TF),
-               "phase_ms_per_step": {"rollout": phase["rollout_s"] / args.steps * 1e3, "update": (dt - phase["rollout_s"]) / args.steps * 1e3},
+               "phase_ms_per_step": {"rollout": phase["rollout_s"] / args.steps * 1e3, "update": (dt - phase["rollout_s"]) / args.steps * 1e3,
+                                     "update_host_enqueue": phase["update_enqueue_s"] / args.steps * 1e3},
                "kernel_profile_period": (0 if args.no_kernel_profile else max(1, args.profile_period)),    # kernels[]: the bracketed sample only
                "kernels": sorted(prof, key=lambda r: -r["ms"])[:24],
                "loss_total": summary["Loss/total"]}

@@ -14,12 +14,15 @@ from common.policy import CategoricalPolicy
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 h2d = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
+flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 T, A = 256, 15
 torch.manual_seed(0)
 pol = CategoricalPolicy(ImpalaModel(3), False, A)
 eng = Engine("impala", T, E, A, E, precision="bf16")
 eng.set_params(layout.flatten(layout.impala_param_shapes(A), {k: v.detach().numpy() for k, v in pol.state_dict().items()}))
 eng.rollout_groups(G)
+if flags:
+    eng.debug_flags(flags)
 ng = E // G
 rng = np.random.default_rng(0)
 fr = [[eng.pinned((ng, 64, 64, 3), np.uint8) for _ in range(4)] for _ in range(G)]
