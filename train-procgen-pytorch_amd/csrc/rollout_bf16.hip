@@ -122,25 +122,28 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
 
     // Bank k lives in LDS buffer k & 1 and travels through register set k & 1: fetched TWO convs ahead of its use (a conv phase is
     // ~0.5 us, an L2 round trip ~1 us: one conv of lead left every commit waiting for its loads), written to LDS at the end of conv k - 1.
-    uint4 wreg[2][KW];
+    // (staging registers are ext-vector typed: a copy of the HIP uint4 STRUCT from global to a local array and on to LDS compiles to memcpy
+    //  through a private array, i.e. through scratch memory)
+    typedef unsigned rt_u32x4 __attribute__((ext_vector_type(4)));
+    rt_u32x4 wreg[2][KW];
     auto bank_fetch = [&](int k) {
         const int words = (k == 0 ? 32 * WS16 : W_ELEMS) / 8;
 #pragma unroll
-        for (int q = 0; q < KW; ++q) { const int e = tid + q * NT; wreg[k & 1][q] = e < words ? ((const uint4*)a.bank[k])[e] : (uint4){0u, 0u, 0u, 0u}; }
+        for (int q = 0; q < KW; ++q) { const int e = tid + q * NT; wreg[k & 1][q] = e < words ? ((const rt_u32x4*)a.bank[k])[e] : (rt_u32x4){0u, 0u, 0u, 0u}; }
     };
     auto bank_commit = [&](int k) {
         const int words = (k == 0 ? 32 * WS16 : W_ELEMS) / 8;
 #pragma unroll
-        for (int q = 0; q < KW; ++q) { const int e = tid + q * NT; if (e < words) ((uint4*)s_w[k & 1])[e] = wreg[k & 1][q]; }
+        for (int q = 0; q < KW; ++q) { const int e = tid + q * NT; if (e < words) ((rt_u32x4*)s_w[k & 1])[e] = wreg[k & 1][q]; }
     };
     // end of conv c (c >= 1): bank c + 1 goes to LDS (its buffer's previous bank, c - 1, was last read in conv c - 1), bank c + 3 is requested
     auto bank_step = [&](int c) { bank_commit(c + 1); if (c + 3 <= 9) bank_fetch(c + 3); };
 
     for (int img = blockIdx.x; img < a.n; img += gridDim.x) {
         // ---- every first load of the image is requested before anything waits: the frame (4 words per thread), banks 0 / 1, the biases
-        uint4 xin[2048 / NT];
+        rt_u32x4 xin[2048 / NT];
         {
-            const uint4* g = (const uint4*)(a.x + (long long)img * 32 * 32 * 16);
+            const rt_u32x4* g = (const rt_u32x4*)(a.x + (long long)img * 32 * 32 * 16);
 #pragma unroll
             for (int q = 0; q < 2048 / NT; ++q) xin[q] = g[tid + q * NT];
         }
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
 #pragma unroll
         for (int q = 0; q < 2048 / NT; ++q) {               // 2048 words of 8 channels: (row, col, half)
             const int e = tid + q * NT, c8 = e & 1, px = (e >> 1) & 31, r = e >> 6;
-            *(uint4*)(s_in + ((r + 1) * P32 + px + 1) * S16 + c8 * 8) = xin[q];
+            *(rt_u32x4*)(s_in + ((r + 1) * P32 + px + 1) * S16 + c8 * 8) = xin[q];
         }
         __syncthreads();
 
