@@ -107,8 +107,12 @@ def rocprof_name(cls, precision):
     if parts[0] == "resblock":                        # fused residual block (bf16 mode): RbCfg<C, HW, TH, NIMG>, BWD
         if kind == "dgrad" and cin == 16:             # 16-channel blocks: data + weight gradients in one kernel
             return ["resblock_bwd_full_bf16_kernel"]
-        if kind == "dgrad" and hw == 16:              # 32-channel blocks @16x16: likewise (512-thread workgroups)
-            return ["resblock_bwd_full32_bf16_kernel"]
+        if kind == "dgrad" and hw == 16:              # 32-channel blocks @16x16: likewise (wave-specialised 512-thread workgroups)
+            return ["resblock_bwd_full32"]
+        if kind == "dgrad" and hw == 8:
+            return ["resblock_bwd_full32_bf16_kernel<RbFull32T<8"]
+        if kind == "fwd":                             # res1 + res2 of a block in one launch
+            return [f"resblock_pair_bf16_kernel<RbCfg<{cin}, {hw},"]
         return [f"resblock_bf16_kernel<RbCfg<{cin}, {hw},", ", true>" if kind == "dgrad" else ", false>"]
     if precision == "bf16":
         if cin == 3:
@@ -117,6 +121,8 @@ def rocprof_name(cls, precision):
             return [f"conv3x3_wgrad_bf16_kernel<WbCfg<{cin}, {cout}, {hw},", ", true>" if cin != cout else ", false>"]      # class is dominated by the res convs)
         if kind == "fwd":                             # the block's first conv, fused with the max pool
             return [f"conv_pool_fwd_bf16_kernel<CpCfg<{cin}, {cout}, {hw}>"]
+        if cin == 16 and cout == 32:                  # block2.conv: data + weight gradient from the pooled gradient, dedicated kernel
+            return ["block2_conv_bwd_bf16_kernel"]
         return [f"conv3x3_bf16_kernel<BfCfg<{cout}, {cin}, {hw},", "true>, true>" if cin != cout else "true>, false>"]
     if cin == 3:
         return ["conv3x3_wgrad_kernel<WgCfg<3, 4, 16, 64"] if kind == "wgrad" else ["conv3x3_kernel<FwdCfg<3, 4, 16, 64"]
@@ -129,18 +135,19 @@ def rocprof_name(cls, precision):
 
 def pmc_traffic(cls, precision):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the
-    gfx950 correction + WRITE_SIZE; profiles/r01_pmc_<precision>.json, collected on 8192-sample launches by
+    gfx950 correction + WRITE_SIZE; profiles/r0N_pmc_<precision>.json, collected on 8192-sample launches by
     scratch/pmc_workload.py).  None when no committed counter summary matches."""
-    try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_{precision}.json")))
-    except Exception:
-        return None
     keys = rocprof_name(cls, precision)
-    for name, v in tab.items():
-        if all(k in name for k in keys):
-            return dict(bytes_per_launch=(v["hbm_read_MB_per_call"] + v["hbm_write_MB_per_call"]) * 1048576.0,
-                        read_MB=v["hbm_read_MB_per_call"], write_MB=v["hbm_write_MB_per_call"],
-                        source=f"profiles/r01_pmc_{precision}.json", rocprof_kernel=name)
+    for rnd in ("r02", "r01"):                      # the newest committed counter summary that has this kernel
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{precision}.json")))
+        except Exception:
+            continue
+        for name, v in tab.items():
+            if all(k in name for k in keys):
+                return dict(bytes_per_launch=(v["hbm_read_MB_per_call"] + v["hbm_write_MB_per_call"]) * 1048576.0,
+                            read_MB=v["hbm_read_MB_per_call"], write_MB=v["hbm_write_MB_per_call"],
+                            source=f"profiles/{rnd}_pmc_{precision}.json", rocprof_kernel=name)
     return None
 
 
