@@ -373,13 +373,16 @@ def test_fused_rollout_tail_equals_the_four_launches(n):
         assert np.array_equal(a, b) and np.array_equal(a, c)
 
 
-def test_fc_bf16_matrix_core_path_matches_small_batch_path():
-    """Minibatches of >= 1024 samples route embedder.fc through the bf16-MFMA NT/TN kernels (fc_bf16.hip); smaller
-    ones through the fp32-MFMA GEMM on the same bf16-stored activations.  One 1024-sample minibatch must equal the
-    same samples fed as two accumulated halves (n_global = 1024 both times) up to the bf16 rounding of d(feat)."""
+@pytest.mark.parametrize("T,B", [(16, 1024), (18, 1152), (17, 1088)])
+def test_fc_bf16_matrix_core_path_matches_small_batch_path(T, B):
+    """Minibatches of >= 1024 samples route embedder.fc through the bf16-MFMA kernels of fc_bf16.hip (dedicated forward for n % 64 == 0,
+    dedicated data gradient for n % 128 == 0, the tiled NT kernel otherwise, TN weight gradient); smaller ones through the fp32-MFMA
+    GEMM on the same bf16-stored activations.  One B-sample minibatch must equal the same samples fed as two accumulated halves
+    (n_global = B both times) up to the bf16 rounding of d(feat).  1152 = 18 / 9 row blocks: the XCD block map's partial last group;
+    1088: dedicated forward + NT data gradient."""
     from mi355 import engine as M, layout
     from mi355.engine import Engine
-    T, E, A, B = 16, 64, 15, 1024
+    E, A = 64, 15
     rng = np.random.default_rng(3)
     frames = rng.integers(0, 256, size=(T + 1, E, 64, 64, 3), dtype=np.uint8)
     shapes = layout.impala_param_shapes(A)
@@ -399,7 +402,7 @@ def test_fc_bf16_matrix_core_path_matches_small_batch_path():
         eng.compute_estimates(0.999, 0.95, True, True)
         idx = np.random.default_rng(5).permutation(T * E)
         if split:
-            eng.minibatch(idx[:512], B, eng.hparams()); eng.minibatch(idx[512:], B, eng.hparams())
+            eng.minibatch(idx[:B // 2], B, eng.hparams()); eng.minibatch(idx[B // 2:], B, eng.hparams())
             log = eng.loss_log()
             recs.append(log[0] + log[1])                      # each record is that half's share of the B-sample means
         else:

@@ -223,37 +223,14 @@ __device__ __forceinline__ void bf_tile_store(const uint4 (&r)[C::NLD], unsigned
 
 // POOLIN (data gradient of a block's first conv): a.in is the POOLED gradient, a.pool_arg the arg-max bytes; the haloed
 // tile of the conv-output gradient is rebuilt in LDS by PoolStage::gather instead of being loaded.
-// WG (with POOLIN; block2.conv): the same launch also accumulates the conv's weight / bias gradient -- its A operand (the
-// conv-output gradient) is the tile the gather just built, so max-pool backward runs once for both gradients; the forward
-// input tile a.wg_in is staged next to it, operands through ds_read_b64_tr_b16, 18 accumulator tiles (forward cout 32 x
-// cin 16 x 9 taps) kept across the persistent loop, pixel steps dealt to the waves, waves summed through LDS at the end.
-template <class C>
-struct BfWg {                                                              // forward conv: cin_f = C::COUT, cout_f = C::CIN
-    static constexpr int CF_IN = C::COUT, CF_OUT = C::CIN, SX = 16;        // staged forward-input pixel stride (16 channels)
-    static constexpr int XI_ELEMS = C::PH * C::PW * SX, NXI = C::PH * C::TW * (CF_IN / 8), KXI = (NXI + 255) / 256;
-    static constexpr int NSTEP = C::TH * C::TW / 32, NCB = CF_OUT / 16;
-    static constexpr int WLEN = CF_OUT * 9 * CF_IN, SLAB = WLEN + CF_OUT;
-    static constexpr size_t RED_BYTES = (size_t)(WLEN + 4 * CF_OUT) * 4;
-};
-#ifdef BF_TIMING       // scratch/kbench_cb.hip: per-phase shader-clock totals of wave 0 of every workgroup (fused block2.conv backward)
-__device__ unsigned long long g_bf_timing[16];
-#define BTCK(k) do { if (WG && threadIdx.x == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
-#else
-#define BTCK(k) do { } while (0)
-#endif
-template <class C, bool POOLIN = false, bool WG = false>
-__global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(ConvArgs a) {
-#ifdef BF_TIMING
-    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
-#endif
+// (block2.conv, whose weight gradient shares this gather, has its own kernel below: block2_conv_bwd_bf16_kernel)
+template <class C, bool POOLIN = false>
+__global__ __launch_bounds__(256, C::WPE) void conv3x3_bf16_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_in = smem_h;
     unsigned short* s_w = smem_h + C::IN_ELEMS;
     using PS = PoolStage<C::CIN, C::HW / 2, C::TH / 2 + 3>;                // pooled rows ty0/2 - 1 .. ty0/2 + TH/2 + 1
     unsigned short* s_pd = s_w + C::W_ELEMS;
-    using W = BfWg<C>;
-    static_assert(!WG || (POOLIN && W::CF_IN == 16 && W::NCB == 2 && W::NSTEP % 4 == 0), "fused weight gradient: block2.conv shape");
-    unsigned short* s_xi = s_pd + PS::PD_ELEMS + (PS::PD_ELEMS + 1) / 2;   // WG: forward-input tile [PH][PW][16] after the pooled stage (bf16 + bytes)
     static_assert(!POOLIN || (C::NIMG == 1 && C::TW == C::HW && C::TH % 2 == 0), "pooled input: full-width row tiles of one image");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
@@ -298,91 +275,24 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
     PS ps;
     int img0, ty0, tx0;
     if (POOLIN) for (int e = tid; e < C::IN_ELEMS / 8; e += 256) ((uint4*)s_in)[e] = (uint4){0u, 0u, 0u, 0u};      // halo columns stay zero
-    // ---- WG state: forward-input prefetch registers, accumulators
-    uint4 rxi[WG ? W::KXI : 1];
-    f32x4 wacc[WG ? 9 * W::NCB : 1], waccb[WG ? W::NCB : 1];
-    if constexpr (WG) {
-        for (int e = tid; e < W::XI_ELEMS / 8; e += 256) ((uint4*)s_xi)[e] = (uint4){0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < 9 * W::NCB; ++k) wacc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < W::NCB; ++k) waccb[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    auto xi_load = [&](int img, int y0) {                                  // rows y0-1 .. y0+TH, interior columns
-        if constexpr (WG) {
-            const unsigned short* g_xi = (const unsigned short*)a.wg_in;
-#pragma unroll
-            for (int k = 0; k < W::KXI; ++k) {
-                const int e = tid + k * 256;
-                uint4 v = {0u, 0u, 0u, 0u};
-                if (e < W::NXI) { const int c8 = e % 2, px = (e / 2) % C::TW, gy = y0 - 1 + e / (2 * C::TW);
-                                  if (gy >= 0 && gy < C::HW) v = *(const uint4*)(g_xi + (((long long)img * C::HW + gy) * C::HW + px) * W::CF_IN + c8 * 8); }
-                rxi[k] = v;
-            }
-        }
-    };
     if ((int)blockIdx.x < nwork) {
         bf_coords<C>(blockIdx.x, img0, ty0, tx0);
         if constexpr (POOLIN) ps.load(g_in, a.pool_arg, img0, ty0 / 2 - 1); else bf_tile_load<C>(regs, g_in, a.n, img0, ty0, tx0);
-        xi_load(img0, ty0);
     }
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         bf_coords<C>(work, img0, ty0, tx0);
         __syncthreads();
-        BTCK(0);                                                           // epilogue stores + wait at the top barrier
         if constexpr (POOLIN) {
             ps.store(s_pd);
-            if constexpr (WG) {
-#pragma unroll
-                for (int k = 0; k < W::KXI; ++k) {
-                    const int e = tid + k * 256;
-                    if (e < W::NXI) *(uint4*)(s_xi + ((e / (2 * C::TW)) * C::PW + (e / 2) % C::TW + 1) * W::SX + (e % 2) * 8) = rxi[k];
-                }
-            }
             __syncthreads();
-            BTCK(1);                                                       // staging stores (wait for the prefetched loads) + barrier
             PS::gather(s_pd, ty0 / 2 - 1, ty0 - 1, ty0 + C::TH + 1, s_in, ty0 - 1, C::PW, 1, C::S);
-            BTCK(2);                                                       // gather
         } else bf_tile_store<C>(regs, s_in, a.relu_in);
         __syncthreads();
-        BTCK(3);                                                           // barrier after the gather
         if (work + (int)gridDim.x < nwork) {
             int i2, y2, x2;
             bf_coords<C>(work + gridDim.x, i2, y2, x2);
             if constexpr (POOLIN) ps.load(g_in, a.pool_arg, i2, y2 / 2 - 1); else bf_tile_load<C>(regs, g_in, a.n, i2, y2, x2);
-            xi_load(i2, y2);
         }
-        BTCK(4);                                                           // next item's loads issued
-        if constexpr (WG) {            // weight gradient of the forward conv from the two LDS tiles; pixel steps of 32 dealt to the waves
-            const int rq = (lane & 15) >> 2, cp = lane & 3;
-            const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
-            for (int t = wave; t < W::NSTEP; t += 4) {
-                int prow[2];                                               // this lane's two source pixels (tile coordinates, no halo offset)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int pl = 32 * t + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq;
-                    prow[h] = (pl / C::TW) * C::PW + pl % C::TW;
-                }
-                bf16x8 dv[W::NCB];
-#pragma unroll
-                for (int cb = 0; cb < W::NCB; ++cb) {                      // d(conv output) at the pixel: s_in row 0 = ty0-1, col 0 = -1
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_in + (prow[0] + C::PW + 1) * C::S + cb * 16 + 4 * cp));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_in + (prow[1] + C::PW + 1) * C::S + cb * 16 + 4 * cp));
-                    dv[cb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    waccb[cb] = MFMA_BF16(dv[cb], ones, waccb[cb]);
-                }
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {                        // forward input at pixel + tap - (1, 1): s_xi row 0 = ty0-1, col 0 = -1
-                    const int toff = (tap / 3) * C::PW + (tap % 3);
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_xi + (prow[0] + toff) * W::SX + 4 * cp));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(s_xi + (prow[1] + toff) * W::SX + 4 * cp));
-                    const bf16x8 xv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                    for (int cb = 0; cb < W::NCB; ++cb) wacc[tap * W::NCB + cb] = MFMA_BF16(dv[cb], xv, wacc[tap * W::NCB + cb]);
-                }
-            }
-        }
-        BTCK(5);                                                           // weight-gradient MFMAs
         // epilogue operands requested before the MFMA phase (one wave-uniform branch per block of loads)
         uint2 e_mask[C::MT][C::NB], e_res[C::MT][C::NB];
         long long e_off[C::MT];
@@ -442,8 +352,6 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);
         }
-
-        BTCK(6);                                                           // data-gradient MFMAs
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
             if (e_on[mt]) {
@@ -463,39 +371,6 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
                 }
             }
     }
-#ifdef BF_TIMING
-    if (WG && threadIdx.x == 0) for (int q = 0; q < 8; ++q) atomicAdd(&g_bf_timing[q], (unsigned long long)tacc_[q]);
-#endif
-    if constexpr (WG) {                // waves summed through LDS in fixed order; one slab per workgroup: [co_f][tap][ci_f] then the bias sums
-        __syncthreads();
-        float* red = (float*)smem_h;
-        float* redb = red + W::WLEN;
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w) {
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                    for (int cb = 0; cb < W::NCB; ++cb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int o = ((cb * 16 + kq * 4 + r) * 9 + tap) * W::CF_IN + i;
-                            const float v = wacc[tap * W::NCB + cb][r];
-                            red[o] = (w == 0) ? v : red[o] + v;
-                        }
-            }
-            __syncthreads();
-        }
-        if (i == 0) {
-#pragma unroll
-            for (int cb = 0; cb < W::NCB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) redb[wave * W::CF_OUT + cb * 16 + kq * 4 + r] = waccb[cb][r];
-        }
-        __syncthreads();
-        float* slab = a.wg_partial + (long long)blockIdx.x * W::SLAB;
-        for (int e = tid; e < W::WLEN; e += 256) slab[e] = red[e];
-        if (tid < W::CF_OUT) slab[W::WLEN + tid] = (redb[tid] + redb[W::CF_OUT + tid]) + (redb[2 * W::CF_OUT + tid] + redb[3 * W::CF_OUT + tid]);
-    }
 }
 
 // ------------------------------------------------------------------------------------------ block2.conv: whole backward in one launch
@@ -511,9 +386,6 @@ __global__ __launch_bounds__(256, WG ? 2 : C::WPE) void conv3x3_bf16_kernel(Conv
 // bank, s_pd 7 pooled rows (bf16 + arg bytes), s_xi [10][34][16] forward input.  Data gradient: same operand layout and K order as
 // the generic kernel -> bit-identical dX.  Weight gradient: pixel steps {2p, 2p+1} belong to the wave pair (p, p+4); partial sums
 // leave through LDS in fixed wave order, one slab per workgroup.
-#ifndef B2BWD_NEW
-#define B2BWD_NEW 1
-#endif
 struct B2Bwd {
     using C = BfCfg<32, 16, 32, 8, 32, 1, true>;
     using PS = PoolStage<32, 16, 6>;                                        // pooled rows 4k .. 4k+5 of item k
@@ -529,7 +401,8 @@ struct B2Bwd {
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
     static_assert(PS::NW <= NT && PS::NTASK2 == 5 * 256, "one pooled-stage word per thread; 256 two-channel gather tasks per block row");
 };
-#ifdef BF_TIMING
+#ifdef BF_TIMING      // scratch/kbench_cb.hip: per-phase shader-clock totals of wave 0 (slots 0-7) and wave 4 (8-15) of every workgroup
+__device__ unsigned long long g_bf_timing[16];
 #define B2CK(k) do { if ((threadIdx.x & 255) == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
 #else
 #define B2CK(k) do { } while (0)
@@ -1512,29 +1385,26 @@ using BD_16_32_32 = BfCfg<32, 16, 32,  8, 32, 1, true>;
 using BD_32_32_16 = BfCfg<32, 32, 16, 16, 16, 1, true>;
 using BD_32_32_8  = BfCfg<32, 32,  8,  8,  8, 4, true>;
 
-template <class C, bool POOLIN, bool WG>
-static constexpr size_t bf_lds_bytes() {
-    size_t b = C::LDS_BYTES + (POOLIN ? PoolStage<C::CIN, C::HW / 2, C::TH / 2 + 3>::BYTES : 0) + (WG ? (size_t)BfWg<C>::XI_ELEMS * 2 : 0);
-    return (WG && b < BfWg<C>::RED_BYTES) ? BfWg<C>::RED_BYTES : b;
-}
-template <class C, bool POOLIN, bool WG>
+template <class C, bool POOLIN>
+static constexpr size_t bf_lds_bytes() { return C::LDS_BYTES + (POOLIN ? PoolStage<C::CIN, C::HW / 2, C::TH / 2 + 3>::BYTES : 0); }
+template <class C, bool POOLIN>
 static int bf_grid(int n) {
-    int bpc = (int)((160 * 1024) / bf_lds_bytes<C, POOLIN, WG>());
+    int bpc = (int)((160 * 1024) / bf_lds_bytes<C, POOLIN>());
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
     int grid = (C::NIMG > 1) ? (n + C::NIMG - 1) / C::NIMG : n * C::TPI;
     return grid > 256 * bpc ? 256 * bpc : grid;
 }
-template <class C, bool POOLIN = false, bool WG = false>
+template <class C, bool POOLIN = false>
 static void launch_bf_t(const ConvArgs& a, hipStream_t st) {
     static bool attr = false;
-    constexpr size_t LDS = bf_lds_bytes<C, POOLIN, WG>();
-    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<C, POOLIN, WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    constexpr size_t LDS = bf_lds_bytes<C, POOLIN>();
+    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<C, POOLIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
     int bpc = (int)((160 * 1024) / LDS);
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
     int grid = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
     if (grid > 256 * bpc) grid = 256 * bpc;
     if (grid < 1) return;
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<C, POOLIN, WG>), dim3(grid), dim3(256), LDS, st, a);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<C, POOLIN>), dim3(grid), dim3(256), LDS, st, a);
 }
 
 void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
@@ -1549,7 +1419,7 @@ void launch_conv_fwd_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
 void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
     switch (s) {
         case CS_16_16_32: launch_bf_t<BD_16_16_32>(a, st); break;
-        case CS_16_32_32: if (a.pool_arg && a.wg_partial) { if (B2BWD_NEW) launch_block2_conv_bwd(a, st); else launch_bf_t<BD_16_32_32, true, true>(a, st); }
+        case CS_16_32_32: if (a.pool_arg && a.wg_partial) launch_block2_conv_bwd(a, st);
                           else if (a.pool_arg) launch_bf_t<BD_16_32_32, true>(a, st); else launch_bf_t<BD_16_32_32>(a, st); break;
         case CS_32_32_16: if (a.pool_arg) launch_bf_t<BD_32_32_16, true>(a, st); else launch_bf_t<BD_32_32_16>(a, st); break;
         case CS_32_32_8:  launch_bf_t<BD_32_32_8>(a, st); break;
@@ -1557,4 +1427,4 @@ void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
     }
 }
 
-int conv_bwd_fused_grid(ConvShape s, int n) { return s == CS_16_32_32 ? (B2BWD_NEW ? b2bwd_grid(n) : bf_grid<BD_16_32_32, true, true>(n)) : -1; }
+int conv_bwd_fused_grid(ConvShape s, int n) { return s == CS_16_32_32 ? b2bwd_grid(n) : -1; }
