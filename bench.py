@@ -276,16 +276,19 @@ def main():
             for h in hg:
                 h[...] = rng.integers(0, 256, size=h.shape, dtype=np.uint8)
 
-    phase = {"rollout_s": 0.0, "update_enqueue_s": 0.0}
+    phase = {"rollout_s": 0.0, "update_enqueue_s": 0.0, "estimates_host_s": 0.0, "optimize_head_s": 0.0, "optimize_tail_s": 0.0, "last_enq": 0.0, "first_mb": None, "t_opt0": 0.0}
     # host time inside the update's enqueueing calls (no sync in them): next to the update phase's wall time it says whether a box's
     # host kept the GPU fed (a loaded host shows up here, not in the per-kernel times)
     def _timed(fn):
         def w(*a, **k):
             t = time.perf_counter()
+            if phase["first_mb"] is None:                      # optimize() entered -> its first enqueueing call (index permutation, plan)
+                phase["first_mb"] = t; phase["optimize_head_s"] += t - phase["t_opt0"]
             try:
                 return fn(*a, **k)
             finally:
-                phase["update_enqueue_s"] += time.perf_counter() - t
+                phase["last_enq"] = time.perf_counter()
+                phase["update_enqueue_s"] += phase["last_enq"] - t
         return w
     eng.minibatch = _timed(eng.minibatch)
     agent.optimizer.step = _timed(agent.optimizer.step)
@@ -306,8 +309,13 @@ def main():
         for g in range(G):
             eng.rollout_wait(g)
         phase["rollout_s"] += time.perf_counter() - t_r         # every group's last step has been read back: no extra sync
+        t_e = time.perf_counter()
         storage.compute_estimates(hp["gamma"], hp["lmbda"], hp["use_gae"], hp["normalize_adv"], agent.coll)
-        return agent.optimize()
+        phase["estimates_host_s"] += time.perf_counter() - t_e
+        phase["t_opt0"] = time.perf_counter(); phase["first_mb"] = None
+        out = agent.optimize()
+        phase["optimize_tail_s"] += time.perf_counter() - phase["last_enq"]        # last enqueue returned -> optimize() returned (log readback = the sync)
+        return out
 
     def fence():
         if world > 1:
@@ -320,7 +328,8 @@ def main():
     eng.profile_enable(0 if args.no_kernel_profile else ((2 if args.profile_rollout else 1) | (max(1, args.profile_period) << 8)))
     eng.profile_read(reset=True)
     fence()
-    phase["rollout_s"] = 0.0; phase["update_enqueue_s"] = 0.0
+    for k in ("rollout_s", "update_enqueue_s", "estimates_host_s", "optimize_head_s", "optimize_tail_s"):
+        phase[k] = 0.0
     t0 = time.perf_counter()
     for it in range(args.steps):
         summary = iteration(args.warmup + it)
@@ -375,7 +384,10 @@ def main():
                    "mfma_frac": per_gpu * f_step / (mpeak * 1e12)})(value / world, 8.99e6 if args.precision == "bf16" else 17.90e6, 601.78e6,
                                                                    MFMA_BF16_PEAK_TF if args.precision == "bf16" else MFMA_F32_PEAK_TF),
                "phase_ms_per_step": {"rollout": phase["rollout_s"] / args.steps * 1e3, "update": (dt - phase["rollout_s"]) / args.steps * 1e3,
-                                     "update_host_enqueue": phase["update_enqueue_s"] / args.steps * 1e3},
+                                     "update_host_enqueue": phase["update_enqueue_s"] / args.steps * 1e3,
+                                     "update_host_estimates": phase["estimates_host_s"] / args.steps * 1e3,
+                                     "update_host_before_first_enqueue": phase["optimize_head_s"] / args.steps * 1e3,
+                                     "update_after_last_enqueue": phase["optimize_tail_s"] / args.steps * 1e3},
                "kernel_profile_period": (0 if args.no_kernel_profile else max(1, args.profile_period)),    # kernels[]: the bracketed sample only
                "kernels": sorted(prof, key=lambda r: -r["ms"])[:24],
                "loss_total": summary["Loss/total"]}

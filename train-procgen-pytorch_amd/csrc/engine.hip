@@ -146,7 +146,7 @@ struct mi_ctx {
     bool gru_on; float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *h_state, *h_masked, *gru_gi, *gru_gh, *d_done;
     // pinned host staging
     // index staging ring: a slot is rewritten only after the H2D copy that read it has completed
-    static constexpr int IDX_RING = 8;
+    static constexpr int IDX_RING = 32;
     int32_t* h_idx_ring[IDX_RING]; hipEvent_t idx_ev[IDX_RING]; bool idx_used[IDX_RING]; int idx_next;
     float* h_f; int32_t* h_i; size_t h_f_floats;
     int multirank;
