@@ -26,13 +26,16 @@ __device__ __forceinline__ uint2 rb_pack(const float (&v)[4]) {
     return (uint2){mi_pk_bf16(v[0], v[1]), mi_pk_bf16(v[2], v[3])};
 }
 
+#ifndef RB_S32
+#define RB_S32 48         // pixel stride (bf16 elements) of the 32-channel LDS tiles
+#endif
 template <int C_, int HW_, int TH_, int NIMG_, int NT_ = 256>
 struct RbCfg {
     static constexpr int C = C_, HW = HW_, TH = TH_, NIMG = NIMG_, NT = NT_, NW = NT_ / 64;      // NT threads = NW waves per workgroup
     static constexpr bool WHOLE = (TH == HW);                // whole images: no halo rows to recompute
     static_assert(WHOLE || NIMG == 1, "row tiles hold one image");
     static_assert(HW % TH == 0, "tiles cover the image");
-    static constexpr int S = (C == 16) ? 16 : 48;            // conflict-free pixel strides (see conv_bf16.hip)
+    static constexpr int S = (C == 16) ? 16 : RB_S32;        // conflict-free pixel strides (see conv_bf16.hip)
     static constexpr int P = HW + 2;                         // haloed row length
     static constexpr int R1 = WHOLE ? HW : TH + 2;           // rows the first conv is evaluated on (per image)
     static constexpr int XR = R1 + 2;                        // staged input rows
@@ -699,7 +702,7 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
 // L2 instead of LDS measured 410 us per launch: every K step waited ~0.5 us for its filter fragment.)
 template <int HW_, int NT_, int TH_ = 8>
 struct RbFull32T {                               // HW 16: 8-row tiles, 512 threads; HW 8: whole image, 256 threads (79 KB: two per CU)
-    static constexpr int C = 32, HW = HW_, TH = TH_, S = 48, P = HW + 2, TPI = HW / TH, NT = NT_, NW = NT_ / 64;
+    static constexpr int C = 32, HW = HW_, TH = TH_, S = RB_S32, P = HW + 2, TPI = HW / TH, NT = NT_, NW = NT_ / 64;
     static constexpr int XR = TH + 4, YR = TH + 2;
     static constexpr int X_ELEMS = XR * P * S, Y_ELEMS = YR * P * S;
     static constexpr int NK = 9, WS = NK * 32 + 16, W_ELEMS = C * WS;
