@@ -347,8 +347,12 @@ def test_accumulated_minibatches_in_one_pass_equal_one_by_one(precision):
         out.append((steps, summary, calls))
     (t0, s0, c0), (t1, s1, c1) = out
     assert c0 == [[8]] * 16 and c1 == [[8, 8, 8, 8]] * 4
+    # the summary averages the records of all four optimizer steps: steps 2-4 run on parameters that already differ (see below); in bf16
+    # a 1e-8 parameter difference that moves one bf16 rounding of an activation is a 4e-3 relative jump there, so the later records
+    # agree to ~1e-4 only (measured 7.9e-5 on Loss/v), in fp32 to 2e-6
+    stol = 2e-6 if precision == "fp32" else 3e-4
     for k in s0:
-        assert (np.isnan(s0[k]) and np.isnan(s1[k])) or abs(s0[k] - s1[k]) < 2e-6, k
+        assert (np.isnan(s0[k]) and np.isnan(s1[k])) or abs(s0[k] - s1[k]) < stol, k
     # Optimizer step 1 sees identical parameters in both schedules: its accumulated gradient differs by the fp32 summation order
     # only (measured 2.4e-7 absolute at |g| = 14, i.e. 2e-8 relative) and the parameters after it by 1.5e-8.  From there the two
     # runs are two trajectories of a chaotic map: a 1e-8 parameter difference flips single ReLU / max-pool decisions of block 1
@@ -360,7 +364,8 @@ def test_accumulated_minibatches_in_one_pass_equal_one_by_one(precision):
     gn = float(np.sqrt((g0.astype(np.float64) ** 2).sum()))
     assert np.abs(g1 - g0).max() < 2e-7 * gn, (np.abs(g1 - g0).max(), gn)
     np.testing.assert_allclose(p1, p0, rtol=0, atol=1e-7)
-    for s_, tol in ((2, 4e-6), (3, 4e-5), (4, 2e-4)):
+    # (measured with the one-launch heads backward: fp32 3e-8 / 3e-8 / 3.6e-8, bf16 4.5e-8 / 6.5e-5 / 4.0e-4 -- a flipped bf16 rounding is a bigger kick than a flipped ReLU)
+    for s_, tol in (((2, 4e-6), (3, 4e-5), (4, 2e-4)) if precision == "fp32" else ((2, 2e-5), (3, 3e-4), (4, 1e-3))):
         d = np.abs(t1[2 * s_ - 1] - t0[2 * s_ - 1]).max()
         print("optimizer step", s_, "max |dparam|", d)
         assert d < tol, (s_, d)

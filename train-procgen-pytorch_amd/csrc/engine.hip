@@ -838,8 +838,14 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
 // backward from dY (n x (A+1)); gradients accumulate into c->grads
 static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
-    linear_wgrad(c, c->dY, c->feat, 0, c->grads + c->wh_off, c->grads + c->bh_off, n, c->H, c->A + 1);
-    linear_dgrad(c, c->dY, c->params + c->wh_off, impala ? c->feat : nullptr, c->dfeat, n, c->H, c->A + 1);
+    if (c->H <= 256 && c->A + 1 <= 16 && !tl_ws) {        // one launch (+ its slab sum) for the heads' three gradients (misc.hip: heads_bwd_kernel)
+        ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * (c->A + 1) + 2.0 * n * c->H + (double)c->H * (c->A + 1)), 4.0 * n * c->H * (c->A + 1));
+        launch_heads_bwd(c->dY, c->feat, c->params + c->wh_off, impala ? 1 : 0, c->dfeat, c->grads + c->wh_off, c->grads + c->bh_off, c->gemm_ws,
+                         n, c->H, c->A + 1, CUR(c));
+    } else {
+        linear_wgrad(c, c->dY, c->feat, 0, c->grads + c->wh_off, c->grads + c->bh_off, n, c->H, c->A + 1);
+        linear_dgrad(c, c->dY, c->params + c->wh_off, impala ? c->feat : nullptr, c->dfeat, n, c->H, c->A + 1);
+    }
     if (!impala) {
         const size_t L = c->mlp.size();
         const float* dy = c->dfeat;

@@ -436,6 +436,67 @@ void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, float* 
     launch_reduce_slabs(col_ws, gy * 4, N, db, N, nullptr, 0, st);
 }
 
+// ------------------------------------------------------------------------------------------ heads backward in one launch
+// The policy / value heads are one 256 x (A+1) linear layer (policy.py:74-80): their data gradient, weight gradient and bias gradient
+// used to be two GEMM launches (each too small to fill a matrix-core tile grid), a split-K reduce and a two-stage column sum -- five
+// launches of 5-14 us for 67 MFLOP.  One thread per feature column k: for every row of the workgroup's chunk it forms
+// dfeat[s][k] = (feat > 0) * sum_o dY[s][o] W[o][k] (an fmaf chain in output order) and accumulates gW[o][k] += dY[s][o] feat[s][k];
+// threads k < O also sum dY[s][k] (the bias gradient).  One slab per workgroup, added in fixed order by reduce_slabs_kernel.
+// dY rows are read through the constant address space (uniform address -> scalar loads: 16 values per row for the whole workgroup).
+// H <= 256, O <= 16.
+typedef const __attribute__((address_space(4))) float* hb_const_f32p;
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ feat, const float* __restrict__ Wh,
+                                                        int relu_mask, float* __restrict__ dfeat, float* __restrict__ slab, int n, int H, int O) {
+    const int k = threadIdx.x;
+    const int chunk = (n + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * chunk, r1 = min(n, r0 + chunk);
+    float w[16], gw[16], gb = 0.f;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) { w[o] = (o < O && k < H) ? Wh[(long long)o * H + k] : 0.f; gw[o] = 0.f; }
+    const int kk = k < H ? k : H - 1;
+    int s = r0;
+    for (; s + 4 <= r1; s += 4) {                         // 4 rows in flight
+        float f[4], d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = feat[(long long)(s + q) * H + kk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            hb_const_f32p dy = (hb_const_f32p)(dY + (long long)(s + q) * O);
+            float acc = 0.f;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) if (o < O) { const float v = dy[o]; acc = fmaf(v, w[o], acc); gw[o] = fmaf(v, f[q], gw[o]); }
+            d[q] = (relu_mask && !(f[q] > 0.f)) ? 0.f : acc;
+            if (k < O) gb += dY[(long long)(s + q) * O + k];
+        }
+        if (k < H) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dfeat[(long long)(s + q) * H + k] = d[q];
+        }
+    }
+    for (; s < r1; ++s) {
+        const float f = feat[(long long)s * H + kk];
+        hb_const_f32p dy = (hb_const_f32p)(dY + (long long)s * O);
+        float acc = 0.f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) if (o < O) { const float v = dy[o]; acc = fmaf(v, w[o], acc); gw[o] = fmaf(v, f, gw[o]); }
+        if (k < H) dfeat[(long long)s * H + k] = (relu_mask && !(f > 0.f)) ? 0.f : acc;
+        if (k < O) gb += dY[(long long)s * O + k];
+    }
+    float* sl = slab + (long long)blockIdx.x * (O * H + O);
+    if (k < H) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) if (o < O) sl[(long long)o * H + k] = gw[o];
+    }
+    if (k < O) sl[(long long)O * H + k] = gb;
+}
+// gW[O][H] += dY^T feat ; gb[O] += colsum(dY) ; dfeat = (dY W) * (feat > 0 if relu_mask).  ws: >= 256 * (O*H + O) floats.
+void launch_heads_bwd(const float* dY, const float* feat, const float* Wh, int relu_mask, float* dfeat, float* gW, float* gb, float* ws,
+                      int n, int H, int O, hipStream_t st) {
+    if (n <= 0) return;
+    int grid = (n + 31) / 32; grid = grid > 256 ? 256 : grid;          // >= 32 rows per workgroup at the training sizes
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3(grid), dim3(256), 0, st, dY, feat, Wh, relu_mask, dfeat, ws, n, H, O);
+    launch_reduce_slabs(ws, grid, O * H + O, gW, O * H, gb, O, st);
+}
+
 __global__ void gather_rows_kernel(const float* src, const int32_t* idx, long long base, float* dst, int n, int d) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long long)n * d) return;
