@@ -205,7 +205,8 @@ void launch_heads_sample(const float* feat, const float* Wh, const float* bh, in
                          float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st,
                          unsigned* done_ctr = nullptr, unsigned* host_flag = nullptr, unsigned ticket = 0);
 void launch_sumsq(const float* g, long long n, double* out, double* part, hipStream_t st);          // out[0] = sum g^2 (deterministic)
-void launch_adam(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr,
+void launch_sumsq_partials(const float* g, long long n, double* part /* 128 doubles */, hipStream_t st);
+void launch_adam(float* p, float* g, float* m, float* v, long long n, const double* sumsq /* the sum, or npart partial sums */, int npart, float max_norm, float lr,
                  float beta1, float beta2, float eps, float step_size_scale, float bc2_sqrt, float* gnorm_out,
                  hipStream_t st);
 void launch_fill(float* p, long long n, float v, hipStream_t st);
@@ -247,3 +248,5 @@ void launch_reduce_all_slabs(const float* ws, float* grads, const SlabDesc* d_de
 struct BankDesc { long long w_off, out_off; int rows, cin_pass, co_f, ci_f, transw, ws, nk; };
 int  bank_ws(int cin_pass);                 // elements per bank row
 void launch_pack_banks(const float* params, unsigned short* banks, const BankDesc* d_desc, int n_desc, hipStream_t st);
+void launch_repack_all(const float* params, unsigned short* banks, const BankDesc* d_desc, int n_desc, const float* c1_w, unsigned short* c1_bank /* or null */,
+                       const float* fc_w, unsigned short* fc_wp, unsigned short* fc_wt, hipStream_t st);      // the three re-packing launches of an IMPALA bf16 context in one

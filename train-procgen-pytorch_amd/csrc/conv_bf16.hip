@@ -1079,6 +1079,48 @@ void launch_pack_conv1_bank(const float* w, unsigned short* bank, hipStream_t st
     hipLaunchKernelGGL(pack_conv1_bank_kernel, dim3((16 * C1_WS + 255) / 256), dim3(256), 0, st, w, bank);
 }
 int conv1_bank_elems() { return 16 * C1_WS; }
+// Every bf16 image of the parameters in ONE launch after an optimizer step (three launches before): blocks [0, 8 n_desc) the conv filter
+// banks (pack_banks_kernel's element loop, 8 blocks per bank), the next few block1.conv's bank, the rest embedder.fc's two packed
+// images ([256][2048] for the forward, [2048][256] for the data gradient; fc_bf16.hip).
+__global__ void repack_all_kernel(const float* __restrict__ params, unsigned short* __restrict__ banks, const BankDesc* __restrict__ desc, int n_desc,
+                                  const float* __restrict__ c1_w, unsigned short* __restrict__ c1_bank,
+                                  const float* __restrict__ fc_w, unsigned short* __restrict__ fc_wp, unsigned short* __restrict__ fc_wt) {
+    constexpr int C1B = (16 * C1_WS + 255) / 256;
+    int b = blockIdx.x;
+    if (b < 8 * n_desc) {
+        const BankDesc d = desc[b >> 3];
+        const float* w = params + d.w_off;                // forward layout [co_f][9][ci_f]
+        unsigned short* out = banks + d.out_off;
+        for (int e = (b & 7) * 256 + threadIdx.x; e < d.rows * d.ws; e += 8 * 256) {
+            const int j = e / d.ws, k = e % d.ws, tap = k / d.cin_pass, ci = k % d.cin_pass;
+            float v = 0.f;
+            if (k < d.nk * 32 && tap < 9) v = d.transw ? w[(ci * 9 + (8 - tap)) * d.ci_f + j] : w[(j * 9 + tap) * d.ci_f + ci];
+            out[e] = f2bf(v);
+        }
+        return;
+    }
+    b -= 8 * n_desc;
+    if (b < C1B) {
+        const int e = b * 256 + threadIdx.x;
+        if (c1_bank && e < 16 * C1_WS) {
+            const int j = e / C1_WS, k = e % C1_WS, tap = k / 4, ci = k % 4;
+            c1_bank[e] = f2bf((k < 36 && ci < 3) ? c1_w[(j * 9 + tap) * 3 + ci] : 0.f);
+        }
+        return;
+    }
+    b -= C1B;
+    const int e = b * 256 + threadIdx.x;                   // embedder.fc: N = 256 rows of K = 2048
+    if (e < 256 * 2048) {
+        const unsigned short h = f2bf(fc_w[e]);
+        fc_wp[e] = h;                                      // [n][k]
+        fc_wt[(long long)(e % 2048) * 256 + e / 2048] = h; // [k][n]
+    }
+}
+void launch_repack_all(const float* params, unsigned short* banks, const BankDesc* d_desc, int n_desc, const float* c1_w, unsigned short* c1_bank,
+                       const float* fc_w, unsigned short* fc_wp, unsigned short* fc_wt, hipStream_t st) {
+    const int blocks = 8 * n_desc + (16 * C1_WS + 255) / 256 + 256 * 2048 / 256;
+    hipLaunchKernelGGL(repack_all_kernel, dim3(blocks), dim3(256), 0, st, params, banks, d_desc, n_desc, c1_w, c1_bank, fc_w, fc_wp, fc_wt);
+}
 __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, const unsigned short* lut16, unsigned short* p_out, uint8_t* p_arg) {
     __shared__ __attribute__((aligned(16))) unsigned short s_in[C1P::NPIX * 4];
     __shared__ __attribute__((aligned(16))) unsigned short s_w[16 * C1_WS];

@@ -741,9 +741,8 @@ static void net_gru(mi_ctx* c, int n, int soff = 0) {
 
 static void fc_refresh(mi_ctx* c) {
     if (c->bf && !c->fc_packed_valid) {
-        launch_fc_pack(c->params + c->fc.w_off, c->fc_wp, c->fc_wt, 256, 2048, CUR(c));
-        launch_pack_banks(c->params, c->banks, c->d_bank_desc, c->n_banks, CUR(c));
-        if (c->c1_bank && !c->convs.empty()) launch_pack_conv1_bank(c->params + c->convs[0].w_off, c->c1_bank, CUR(c));
+        launch_repack_all(c->params, c->banks, c->d_bank_desc, c->n_banks, c->convs.empty() ? nullptr : c->params + c->convs[0].w_off,
+                          c->convs.empty() ? nullptr : c->c1_bank, c->params + c->fc.w_off, c->fc_wp, c->fc_wt, CUR(c));
         c->fc_packed_valid = true;
     }
 }
@@ -1476,8 +1475,8 @@ int mi_optimizer_step(mi_ctx* c, float lr, float max_norm, int32_t step, float* 
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     if (c->ar_inflight) { HIPC(hipStreamWaitEvent(c->stream, c->ev_ar_done, 0)); c->ar_inflight = false; }
     c->ar_issued = false; c->ar_armed = false;
-    launch_sumsq(c->grads, c->n_params, c->sumsq, c->sumsq + 2, c->stream);
-    launch_adam(c->params, c->grads, c->adam_m, c->adam_v, c->n_params, c->sumsq, max_norm, lr, (float)b1, (float)b2, 1e-5f,
+    launch_sumsq_partials(c->grads, c->n_params, c->sumsq + 2, c->stream);          // 128 partial sums; the Adam kernel's waves add them up themselves
+    launch_adam(c->params, c->grads, c->adam_m, c->adam_v, c->n_params, c->sumsq + 2, 128, max_norm, lr, (float)b1, (float)b2, 1e-5f,
                 step_size, bc2_sqrt, c->gnorm, c->stream);
     c->fc_packed_valid = false;
     HIPC(hipGetLastError()); NETCHK(c);

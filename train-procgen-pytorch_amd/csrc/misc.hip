@@ -1249,11 +1249,20 @@ void launch_sumsq(const float* g, long long n, double* out, double* part /* >= 1
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(128), dim3(256), 0, st, g, n, part);
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, (const double*)part, 128, out);
 }
-__global__ void adam_kernel(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr_unused,
+// npart > 0: `sumsq` holds the npart fixed-chunk partial sums of launch_sumsq_partials and every wave adds them up itself, in exactly
+// sumsq_final_kernel's order (lane k takes k, k + 64, ...; shuffle tree) -- one launch less per optimizer step, same bits
+__global__ void adam_kernel(float* p, float* g, float* m, float* v, long long n, const double* sumsq, int npart, float max_norm, float lr_unused,
                             float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float* gnorm_out) {
 #pragma clang fp contract(off)
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const float norm = (float)sqrt(sumsq[0]);
+    double total;
+    if (npart > 0) {
+        double t = 0.0;
+        for (int q = threadIdx.x & 63; q < npart; q += 64) t += sumsq[q];
+        t = wave_sum(t);
+        total = __shfl(t, 0, 64);
+    } else total = sumsq[0];
+    const float norm = (float)sqrt(total);
     float coef = max_norm / (norm + 1e-6f);
     coef = coef > 1.f ? 1.f : coef;
     if (k == 0 && gnorm_out) gnorm_out[0] = norm;
@@ -1267,10 +1276,13 @@ __global__ void adam_kernel(float* p, float* g, float* m, float* v, long long n,
     m[k] = mk; v[k] = vk;
     g[k] = 0.f;                                          // optimizer.zero_grad()
 }
-void launch_adam(float* p, float* g, float* m, float* v, long long n, const double* sumsq, float max_norm, float lr,
+void launch_adam(float* p, float* g, float* m, float* v, long long n, const double* sumsq, int npart, float max_norm, float lr,
                  float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float* gnorm_out, hipStream_t st) {
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, sumsq, max_norm, lr,
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, sumsq, npart, max_norm, lr,
                        beta1, beta2, eps, step_size, bc2_sqrt, gnorm_out);
+}
+void launch_sumsq_partials(const float* g, long long n, double* part /* 128 doubles */, hipStream_t st) {
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(128), dim3(256), 0, st, g, n, part);
 }
 
 // ------------------------------------------------------------------------------------------ GRU cell (rollout only)
