@@ -168,7 +168,7 @@ int mi_loss_log_read(mi_ctx* ctx, float* out, int32_t max_records, int32_t* n_re
  *      when nothing was armed).  mi_optimizer_step waits for the exchange on the device (no host sync).
  *      C2: mi_adv_normalize_global = advantage statistics {count, mean, M2} all-gathered in fp64, merged and applied on the device.
  *      C3 / logging: mi_allreduce_buffer sums the first n floats of MI_PTR_LOSS_STATS / MI_PTR_STATS_RING on the context's stream. */
-enum { MI_PTR_GRADS = 0, MI_PTR_LOSS_STATS = 1, MI_PTR_PARAMS = 2, MI_PTR_STATS_RING = 3 };
+enum { MI_PTR_GRADS = 0, MI_PTR_LOSS_STATS = 1, MI_PTR_PARAMS = 2, MI_PTR_STATS_RING = 3, MI_PTR_FS_KEYS = 4 };
 int mi_comm_unique_id(void* out128, size_t bytes);
 int mi_comm_init(mi_ctx* ctx, const void* id128, size_t bytes, int32_t rank, int32_t world);
 int mi_comm_destroy(mi_ctx* ctx);
@@ -182,6 +182,12 @@ int mi_device_ptr(mi_ctx* ctx, int32_t which, void** ptr, int64_t* n_floats);
 /* two-phase loss finalisation for multi-rank runs (phase 2 after the cross-rank sum of the stats) */
 int mi_set_multirank(mi_ctx* ctx, int32_t enabled);   /* 0 single rank; 1 stats all-reduced per minibatch (mi_minibatch_finish); 2 deferred */
 int mi_minibatch_finish(mi_ctx* ctx);      /* multirank mode 1: phase 2 + backward after the stats all-reduce */
+/* fs_coef != 0 on more than one rank (IMPALA, multirank mode 1; SURVEY 8(e) C3 -- reference agents/ppo.py:148-169, common/model.py:207 on the
+ * GLOBAL minibatch): before mi_minibatch, hand over the global minibatch position of every local row (ascending); mi_minibatch then
+ * leaves this rank's per-column candidates (value bits << 32 | 0xffffffff - position, 2048 int64) in MI_PTR_FS_KEYS; max-all-reduce them
+ * (mi_allreduce_buffer(MI_PTR_FS_KEYS, 2048), or torch.distributed on the aliased buffer) before mi_minibatch_finish, which adds the
+ * gradient on the rank that owns each column's winning row and logs the global metric. */
+int mi_minibatch_positions(mi_ctx* ctx, const int32_t* global_positions, int32_t n);
 /* multirank mode 2 (x_entropy_coef == 0 and fs_coef == 0: the backward pass needs no cross-rank statistic): mi_minibatch runs to
  * completion, this rank's partial loss sums of minibatch k go to ring slot k (MI_PTR_STATS_RING, 32 floats each); once per
  * optimize() the caller sums the first 32 * n_minibatches floats over the ranks and calls mi_loss_log_finalize. */

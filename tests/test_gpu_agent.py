@@ -377,6 +377,7 @@ rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.ar
 sys.path[:0] = [sys.argv[5], sys.argv[6]]
 precision = sys.argv[7] if len(sys.argv) > 7 else "fp32"
 xcoef = float(sys.argv[8]) if len(sys.argv) > 8 else 0.02
+fscoef = float(sys.argv[9]) if len(sys.argv) > 9 else 0.0
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -392,7 +393,7 @@ policy = CategoricalPolicy(ImpalaModel(3), False, A)
 storage = Storage((3, 64, 64), 256, T, E, torch.device("cuda", 0))
 class L: episode_reward_buffer = [0.0]; logdir = "/tmp"
 agent = PPO(None, policy, L(), storage, torch.device("cuda", 0), 1, n_steps=T, n_envs=E, epoch=1, n_minibatch=1,
-            mini_batch_size=16, gamma=0.999, lmbda=0.95, learning_rate=5e-4, x_entropy_coef=xcoef, precision=precision)
+            mini_batch_size=16, gamma=0.999, lmbda=0.95, learning_rate=5e-4, x_entropy_coef=xcoef, fs_coef=fscoef, precision=precision)
 rng = np.random.default_rng(0)
 frames = rng.integers(0, 256, size=(T + 1, EG, 64, 64, 3), dtype=np.uint8)
 act = rng.integers(0, A, (T, EG)); logp = (np.log(1 / A) + 0.2 * rng.standard_normal((T, EG))).astype(np.float32)
@@ -409,14 +410,15 @@ adv = eng.read_field(M.F_ADV)
 torch.manual_seed(5)
 summary = agent.optimize()
 if rank == 0:
-    np.savez(out, params=eng.get_params(), adv=adv, total=summary["Loss/total"], xent=summary["Loss/x_entropy"])
+    np.savez(out, params=eng.get_params(), adv=adv, total=summary["Loss/total"], xent=summary["Loss/x_entropy"], fs=summary["Loss/feature_sparsity"])
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("precision,xcoef", [("fp32", 0.02), ("bf16", 0.02), ("fp32", 0.0), ("bf16", 0.0)])
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path, precision, xcoef):
+@pytest.mark.parametrize("precision,xcoef,fscoef", [("fp32", 0.02, 0.0), ("bf16", 0.02, 0.0), ("fp32", 0.0, 0.0), ("bf16", 0.0, 0.0),
+                                                    ("fp32", 0.0, 0.05), ("bf16", 0.02, 0.05)])
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path, precision, xcoef, fscoef):
     """The real multi-rank engine path (mi_set_multirank, loss-stats + gradient all-reduce on aliased device
     buffers, merged advantage statistics) with 2 processes sharing the GPU over `gloo`, against the 1-process run
     on the same global rollout and the same permutation stream: one optimizer step fed by two accumulated
@@ -425,20 +427,29 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, precision, xcoef):
     bf16: every sample's activations are the same whichever rank computes them (the fused kernels work per image); only the fp32
     summation order of the weight gradients differs, as in fp32.
     xcoef = 0.02 takes multirank mode 1 (loss statistics all-reduced per minibatch, the x-entropy gradient needs them); xcoef = 0
-    takes mode 2 (statistics ring reduced once per optimize(), mi_loss_log_finalize)."""
+    takes mode 2 (statistics ring reduced once per optimize(), mi_loss_log_finalize).
+    fscoef != 0: mode 1 plus the max-all-reduce of the per-column (value, global position) candidates -- the gradient of
+    fs_coef * mean_j max_b tanh(|100 h_bj|) lands on the globally first row attaining each column maximum, whichever rank holds it, and
+    the logged metric is the global one."""
     script = tmp_path / "two_rank.py"
     script.write_text(_TWO_RANK)
     port = str(29600 + os.getpid() % 1000)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = str(tmp_path / "one.npz"); two = str(tmp_path / "two.npz")
-    subprocess.run([sys.executable, str(script), "0", "1", port, one, ROOT, PKG, precision, str(xcoef)], check=True, env=env, timeout=300)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, two, ROOT, PKG, precision, str(xcoef)], env=env) for r in range(2)]
+    subprocess.run([sys.executable, str(script), "0", "1", port, one, ROOT, PKG, precision, str(xcoef), str(fscoef)], check=True, env=env, timeout=300)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, two, ROOT, PKG, precision, str(xcoef), str(fscoef)], env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     a, b = np.load(one), np.load(two)
     np.testing.assert_allclose(b["adv"], a["adv"][:, :4], rtol=0, atol=2e-6)        # rank 0 owns envs 0..3
     assert abs(float(a["total"]) - float(b["total"])) < 1e-5 and abs(float(a["xent"]) - float(b["xent"])) < 1e-6
     np.testing.assert_allclose(b["params"], a["params"], rtol=0, atol=2e-6)
+    if fscoef:          # the logged metric is that of the GLOBAL minibatch on both sides (with fs_coef == 0 a rank logs its own rows' metric)
+        assert abs(float(a["fs"]) - float(b["fs"])) < 1e-6 and float(a["fs"]) > 0.01
+        # ... and the term is not a no-op here: the same step without it ends elsewhere
+        off = str(tmp_path / "off.npz")
+        subprocess.run([sys.executable, str(script), "0", "1", port, off, ROOT, PKG, precision, str(xcoef), "0.0"], check=True, env=env, timeout=300)
+        assert np.abs(np.load(off)["params"] - a["params"]).max() > 1e-4
     assert np.abs(a["params"] - b["params"]).max() > 0 or True
 
 

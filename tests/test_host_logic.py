@@ -193,3 +193,29 @@ def test_frame_byte_to_bf16_needs_no_table():
     quotient = (k / 255.0).bfloat16()
     product = (k * torch.tensor(1.0 / 255.0, dtype=torch.float32)).bfloat16()
     assert torch.equal(quotient.view(torch.int16), product.view(torch.int16))
+
+
+def test_update_plan_positions_are_the_rows_places_in_the_global_minibatch():
+    """fs_coef != 0 on several ranks: a pass carries, for every local sample, its position in the global minibatch --
+    ascending, disjoint between the ranks, together covering 0 .. B-1, and mapping the local indices back to the chunk's entries."""
+    from mi355.dist import update_plan, shard_indices
+    T, EG, B, world = 8, 16, 32, 4
+    torch.manual_seed(3)
+    chunks = [torch.randperm(T * EG).numpy()[k * B:(k + 1) * B] for k in range(4)]
+    seen = [np.zeros(B, int) for _ in chunks]
+    for rank in range(world):
+        ops = list(update_plan(iter(chunks), rank, world, EG, 1, False, True, B, with_positions=True))
+        mbs = [op for op in ops if op[0] == "minibatch"]
+        assert len(mbs) == len(chunks) and [op[0] for op in ops].count("stats") == len(chunks)
+        for k, (_, local, seg_n, n_global, pos) in enumerate(mbs):
+            assert n_global == B and seg_n == [len(local)] and len(pos) == len(local) and pos.dtype == np.int32
+            assert np.all(np.diff(pos) > 0)
+            seen[k][pos] += 1
+            e_per = EG // world
+            glob = chunks[k][pos]                                  # the global flat indices at those positions ...
+            t, e = glob // EG, glob % EG
+            assert np.all(e // e_per == rank)                      # ... belong to this rank's env range
+            np.testing.assert_array_equal(local, t * e_per + (e - rank * e_per))      # and are its local indices, in order
+            np.testing.assert_array_equal(local, shard_indices(chunks[k], EG, rank, world))
+    for s in seen:
+        assert np.all(s == 1)

@@ -14,7 +14,7 @@ import torch
 from common.misc_util import adjust_lr, adjust_lr_grok
 from common.model import as_device_obs
 from mi355.dist import Collective, DevicePointerTensor, update_plan
-from mi355.engine import Engine, PTR_GRADS, PTR_LOSS_STATS, PTR_STATS_RING
+from mi355.engine import Engine, PTR_FS_KEYS, PTR_GRADS, PTR_LOSS_STATS, PTR_STATS_RING
 
 
 def _with_next(it):
@@ -62,9 +62,8 @@ class PPO(BaseAgent):
 
         # ---- data parallel over n_envs: this process owns n_envs envs; the global minibatch spans all ranks
         self.coll = Collective()
-        if fs_coef != 0. and self.coll.active:
-            raise NotImplementedError("fs_coef != 0 on more than one rank: the feature-sparsity term needs the column maxima of the GLOBAL "
-                                      "minibatch before the backward pass (max / arg-min exchange, SURVEY 8(e) C3) -- not built")
+        if fs_coef != 0. and self.coll.active and policy.arch != "impala":
+            fs_coef = self.fs_coef = 0.                            # (no feature-sparsity term without the IMPALA feature map, model.py:976-977)
         self.n_envs_global = n_envs * self.coll.world
         n_total = n_steps * self.n_envs_global
         batch_size = n_total // n_minibatch
@@ -109,6 +108,10 @@ class PPO(BaseAgent):
             self._stats_t = DevicePointerTensor(sp, sn).tensor(dev_index)
             rp, rn = self.engine.device_ptr(PTR_STATS_RING)
             self._ring_t = DevicePointerTensor(rp, rn).tensor(dev_index)
+            self._fskeys_t = None
+            if fs_coef != 0. and arch == "impala":                 # per-column candidates, max-all-reduced before the backward pass
+                kp, kn = self.engine.device_ptr(PTR_FS_KEYS)
+                self._fskeys_t = DevicePointerTensor(kp, kn, "<i8").tensor(dev_index)
         self._stage = [self.engine.pinned((n_envs,) + self._obs_stage_shape(arch, emb), self._obs_dtype(arch)) for _ in range(2)]
         self._stage_i = 0
         self._gstage = {}
@@ -204,11 +207,16 @@ class PPO(BaseAgent):
                 yield from self.storage.minibatch_index_stream(self.mini_batch_size, recurrent, self.n_envs_global)
 
         native = self._native
+        # fs_coef != 0 on > 1 rank: the rows' positions in the global minibatch travel with every pass (ties between equal column maxima go
+        # to the globally first row) and the per-column candidates are max-all-reduced next to the loss statistics
+        fs_global = coll.active and self.fs_coef != 0 and self.policy.arch == "impala"
         plan = update_plan(chunks(), coll.rank, coll.world, self.n_envs_global, grad_accumulation_steps, merge,
-                           coll.active and not deferred, eng.max_batch)
+                           coll.active and not deferred, eng.max_batch, with_positions=fs_global)
         for op, nxt in _with_next(plan):
             if op[0] == "minibatch":
-                _, local, seg_n, n_global = op
+                _, local, seg_n, n_global = op[:4]
+                if fs_global:
+                    eng.minibatch_positions(op[4])
                 # the LAST pass before an optimizer step hands its gradient regions to the side stream as they become final
                 # (mi_allreduce_arm); with a per-minibatch statistics exchange the backward pass runs inside minibatch_finish (below)
                 if native and nxt is not None and nxt[0] == "step":
@@ -220,9 +228,13 @@ class PPO(BaseAgent):
             elif op[0] == "stats":
                 if native:
                     eng.allreduce_buffer(PTR_LOSS_STATS, 32)
+                    if fs_global:
+                        eng.allreduce_buffer(PTR_FS_KEYS, 2048)
                 else:
                     with torch.cuda.stream(self._tstream):
                         coll.allreduce_sum_(self._stats_t)       # 32 floats: loss sums + mean action probabilities
+                        if fs_global:
+                            coll.allreduce_max_(self._fskeys_t)  # 2048 int64 (value bits, position) candidates
                 if native and nxt is not None and nxt[0] == "step":
                     eng.allreduce_arm()
                 eng.minibatch_finish()

@@ -189,6 +189,12 @@ void launch_loss_finalize_records(const LossArgs& a, int n_rec, float* stats_bas
 void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, double* fs_parts, hipStream_t stream);
 int  fs_groups_per_segment(int n_seg);
 void launch_fs_grad(const void* x, int bf16, int n, int d, const float* part, int G, void* Gd, float fs_coef, float* colmax, int* arg, hipStream_t st);
+// multi-rank feature-sparsity term: per-column 64-bit candidates for ONE max-all-reduce, then the winner applies (misc.hip)
+void launch_fs_keys(const void* x, int bf16, int n, int d, const float* part, int G, const int32_t* gpos, float* colmax, int* arg,
+                    long long* keys, long long* keys_local, hipStream_t st);
+void launch_fs_apply_keys(void* Gd, int bf16, int d, const long long* keys, const long long* keys_local, const int* arg, float fs_coef, hipStream_t st);
+void launch_fs_from_keys(const long long* keys, int d, float* fs_out, hipStream_t st);
+int  fs_metric_groups();
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st);
 
 void launch_gae(const float* rew, const float* done, const float* value, float* adv, float* ret, int T, int E,

@@ -159,6 +159,9 @@ struct mi_ctx {
     struct GroupWorker* gw[MAX_GROUPS];      // one host thread per group issues that group's copies + launches (a step is ~9 API calls = ~30 us of host time)
     bool rollout_tail;          // bf16 inference passes of <= 256 samples run blocks 2 + 3 as one launch (mi_debug_flags bit 0 clears it: A/B tests)
     float *fs_colmax, fs_grad_coef; int *fs_arg, fs_G;      // feature-sparsity gradient (fs_coef != 0): column maxima / first arg-max rows of the minibatch
+    // ... on more than one rank (multirank mode 1): per-column candidates for the max-all-reduce (MI_PTR_FS_KEYS), this rank's own copy, and
+    // the global minibatch positions of the pending pass's rows (mi_minibatch_positions)
+    long long *fs_keys, *fs_keys_local; int32_t *d_gpos, *h_gpos; int gpos_n; bool fs_global_pending, fs_global_apply;
     // data-parallel collectives (RCCL over xGMI), SURVEY 8(e): one communicator per context, a side stream for the gradient all-reduce
     ncclComm_t comm; int comm_world, comm_rank; hipStream_t comm_stream; hipEvent_t ev_ar_ready, ev_ar_done;
     bool ar_armed, ar_issued, ar_inflight; double* adv_all;
@@ -335,6 +338,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         HIPC(hipMalloc((void**)&c->d_slab_desc, sizeof(SlabDesc) * 15)); c->slab_desc_n = 0; c->slab_desc_cached_n = -1;
         HIPC(dalloc(&c->fs_scratch, (size_t)MI_MAX_SEG * 128 * 2048));      // (segments x) FS_GROUPS x 2048 partial column maxima (misc.hip)
         HIPC(dalloc(&c->fs_colmax, (size_t)2048)); HIPC(dalloc(&c->fs_arg, (size_t)2048));
+        HIPC(dalloc(&c->fs_keys, (size_t)2048)); HIPC(dalloc(&c->fs_keys_local, (size_t)2048)); HIPC(dalloc(&c->d_gpos, (size_t)NB));
+        HIPC(hipHostMalloc((void**)&c->h_gpos, (size_t)NB * 4, hipHostMallocDefault));
     } else {
         c->obs_bytes_per_env = (size_t)cfg->obs_dim * sizeof(float);
         HIPC(dalloc(&c->obsf, (size_t)(T + 1) * E * cfg->obs_dim));
@@ -392,7 +397,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stream = nullptr; c->ev_ar_ready = c->ev_ar_done = nullptr;
     c->ar_armed = c->ar_issued = c->ar_inflight = false; c->adv_all = nullptr;
     c->fs_grad_coef = 0.f; c->fs_G = 0; c->rollout_tail = true;
-    if (cfg->arch != MI_ARCH_IMPALA) { c->fs_colmax = nullptr; c->fs_arg = nullptr; }
+    if (cfg->arch != MI_ARCH_IMPALA) { c->fs_colmax = nullptr; c->fs_arg = nullptr; c->fs_keys = c->fs_keys_local = nullptr; c->d_gpos = nullptr; c->h_gpos = nullptr; }
+    c->gpos_n = -1; c->fs_global_pending = c->fs_global_apply = false;
     c->n_groups = 1; c->groups_live = false; c->main_stream = c->stream;
     for (int g = 0; g < mi_ctx::MAX_GROUPS; ++g) { c->gw[g] = nullptr; c->gs[g] = nullptr; c->ev_fork[g] = c->ev_join[g] = nullptr; c->g_forked[g] = c->g_busy[g] = c->g_last[g] = c->g_dirty[g] = false; c->g_ticket[g] = 0; }
     c->multirank = 0; c->pending_n = -1; c->sal_dc = nullptr; c->sal_dx = nullptr; c->sal_src = nullptr;
@@ -453,6 +459,7 @@ int mi_destroy(mi_ctx* c) {
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     if (c->fs_colmax) hipFree(c->fs_colmax); if (c->fs_arg) hipFree(c->fs_arg);
+    if (c->fs_keys) hipFree(c->fs_keys); if (c->fs_keys_local) hipFree(c->fs_keys_local); if (c->d_gpos) hipFree(c->d_gpos); if (c->h_gpos) hipHostFree(c->h_gpos);
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) { hipHostFree(c->h_idx_ring[k]); hipEventDestroy(c->idx_ev[k]); }
     hipHostFree(c->h_f); hipHostFree(c->h_i);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -875,8 +882,10 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         launch_fc_dgrad_bf16(c->dfeat, c->fc_wt, c->blk[2].P2, Gout, n, CUR(c));
     } else
         linear_dgrad(c, c->dfeat, c->params + c->fc.w_off, c->blk[2].P2, Gout, n, 2048, c->H, c->bf);
-    if (c->fs_grad_coef != 0.f)      // + fs_coef * d(feature sparsity) / d(block3 output): one element per column (launch_fs_grad, misc.hip)
-        launch_fs_grad(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_G, Gout, c->fs_grad_coef, c->fs_colmax, c->fs_arg, CUR(c));
+    if (c->fs_grad_coef != 0.f) {    // + fs_coef * d(feature sparsity) / d(block3 output): one element per column (launch_fs_grad, misc.hip)
+        if (c->fs_global_apply) { if (n > 0) launch_fs_apply_keys(Gout, c->bf, 2048, c->fs_keys, c->fs_keys_local, c->fs_arg, c->fs_grad_coef, CUR(c)); }      // the column's winner among the ranks
+        else launch_fs_grad(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_G, Gout, c->fs_grad_coef, c->fs_colmax, c->fs_arg, CUR(c));
+    }
     for (int b = 2; b >= 0; --b) {
         Block& k = c->blk[b];
         const ConvLayer* L = &c->convs[b * 5];
@@ -1376,7 +1385,9 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
     ARG(c->pending_n < 0, "previous multirank minibatch not finished");
     { long long tot = 0; for (int k = 0; k < n_seg; ++k) { ARG(seg_n[k] >= 0, "negative segment"); tot += seg_n[k]; } ARG(tot == n, "segments do not add up to n_idx"); }
     const bool batch_terms = hp->x_entropy_coef != 0.f || hp->fs_coef != 0.f;
-    ARG(hp->fs_coef == 0.f || c->multirank == 0, "fs_coef != 0 needs the column maxima over the GLOBAL minibatch: single-rank only (the max / arg-min exchange of SURVEY 8(e) C3 is not built)");
+    ARG(hp->fs_coef == 0.f || c->multirank != 2, "fs_coef != 0 needs the column maxima over the GLOBAL minibatch before the backward pass: multirank mode 1");
+    ARG(hp->fs_coef == 0.f || c->multirank == 0 || c->cfg.arch != MI_ARCH_IMPALA || c->gpos_n == n,
+        "fs_coef != 0 on several ranks: call mi_minibatch_positions with this pass's global minibatch positions first");
     ARG(n_seg == 1 || (!batch_terms && c->multirank != 1), "several minibatches per call need x_entropy_coef == 0, fs_coef == 0 and multirank mode 0 or 2");
     const int64_t TE = (int64_t)c->T * c->E;
     for (int k = 0; k < n; ++k) ARG(idx[k] >= 0 && idx[k] < TE, "minibatch index out of range");
@@ -1429,6 +1440,12 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
     }
     // mode 1: the cross-rank sum of the statistics comes between the loss forward and backward (mi_minibatch_finish)
     if (impala) launch_fs_metric(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, c->fs_val, c->stream);
+    c->fs_global_pending = impala && hp->fs_coef != 0.f;
+    if (c->fs_global_pending) {      // this rank's per-column candidates; the caller max-all-reduces MI_PTR_FS_KEYS before mi_minibatch_finish
+        if (n > 0) launch_fs_keys(c->blk[2].P2, c->bf, n, 2048, c->fs_scratch, fs_metric_groups(), c->d_gpos, c->fs_colmax, c->fs_arg, c->fs_keys, c->fs_keys_local, c->stream);
+        else { HIPC(hipMemsetAsync(c->fs_keys, 0, 2048 * 8, c->stream)); HIPC(hipMemsetAsync(c->fs_keys_local, 0, 2048 * 8, c->stream)); }
+    }
+    c->gpos_n = -1;
     launch_loss_fwd(a, c->stream);
     launch_loss_finalize(a, loss_blocks(n), 1, nullptr, nullptr, c->stream);
     c->pending = a; c->pending_n = n;
@@ -1443,6 +1460,18 @@ int mi_minibatch_multi(mi_ctx* c, const int64_t* idx, int32_t n, const int32_t* 
     return minibatch_impl(c, idx, n, seg_n, n_seg, n_global, hp);
 }
 
+// Global minibatch positions of the NEXT mi_minibatch's rows (ascending; the rank's share of a global minibatch keeps the global order):
+// needed when fs_coef != 0 on more than one rank -- ties between equal column maxima go to the row that comes first globally.
+int mi_minibatch_positions(mi_ctx* c, const int32_t* gpos, int32_t n) {
+    ARG(c && (gpos || n == 0), "null"); JOIN(c); ARG(c->cfg.arch == MI_ARCH_IMPALA && c->d_gpos, "IMPALA contexts only"); ARG(n >= 0 && n <= c->NB, "n");
+    if (n > 0) {
+        HIPC(hipStreamSynchronize(c->stream));                 // (the pinned staging buffer of the previous call is free; this path is not the fast one)
+        memcpy(c->h_gpos, gpos, (size_t)n * 4);
+        HIPC(hipMemcpyAsync(c->d_gpos, c->h_gpos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    c->gpos_n = n;
+    return 0;
+}
 int mi_set_multirank(mi_ctx* c, int32_t enabled) { ARG(c, "null"); ARG(enabled >= 0 && enabled <= 2, "mode"); c->multirank = enabled; return 0; }
 
 // multirank mode 2: after the caller summed stats_ring[0 .. log_count*32) over the ranks, derive every minibatch's log record
@@ -1458,11 +1487,14 @@ int mi_minibatch_finish(mi_ctx* c) {
     ARG(c, "null"); JOIN(c); ARG(c->pending_n >= 0, "no pending minibatch");
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
     float* slot = c->loss_log + (size_t)c->log_count * 8;
+    if (c->fs_global_pending) launch_fs_from_keys(c->fs_keys, 2048, c->fs_val, c->stream);      // the metric of the GLOBAL minibatch (keys are all-reduced by now)
     launch_loss_finalize(c->pending, 0, 2, impala ? c->fs_val : nullptr, slot, c->stream);
     c->log_count++;
     launch_loss_bwd(c->pending, c->stream);
     InputSrc src = minibatch_src(c);
+    if (c->fs_global_pending) { c->fs_grad_coef = c->pending.hp.fs_coef; c->fs_global_apply = true; }
     net_backward(c, src, c->pending_n);
+    c->fs_grad_coef = 0.f; c->fs_global_apply = false; c->fs_global_pending = false;
     c->pending_n = -1;
     HIPC(hipGetLastError()); NETCHK(c);
     return 0;
@@ -1547,6 +1579,11 @@ int mi_allreduce_grads(mi_ctx* c) {
 }
 int mi_allreduce_buffer(mi_ctx* c, int32_t which, int64_t n) {
     ARG(c, "null"); ARG(c->comm, "no communicator: call mi_comm_init first"); JOIN(c);
+    if (which == MI_PTR_FS_KEYS) {                             // max over the ranks of the per-column candidates
+        ARG(c->fs_keys && n == 2048, "MI_PTR_FS_KEYS: the 2048 keys of an IMPALA context");
+        NCCLC(ncclAllReduce(c->fs_keys, c->fs_keys, 2048, ncclInt64, ncclMax, c->comm, c->stream));
+        return 0;
+    }
     float* p = nullptr; int64_t cap = 0;
     switch (which) {
         case MI_PTR_LOSS_STATS: p = c->loss_stats; cap = 32; break;
@@ -1577,6 +1614,7 @@ int mi_device_ptr(mi_ctx* c, int32_t which, void** ptr, int64_t* n) {
         case MI_PTR_LOSS_STATS: *ptr = c->loss_stats; *n = 32; return 0;
         case MI_PTR_PARAMS: *ptr = c->params; *n = c->n_params; return 0;
         case MI_PTR_STATS_RING: *ptr = c->stats_ring; *n = (int64_t)c->log_cap * 32; return 0;
+        case MI_PTR_FS_KEYS: ARG(c->fs_keys, "IMPALA contexts only"); *ptr = c->fs_keys; *n = 2048; return 0;      // 2048 int64 keys
         default: return fail(-1, "unknown pointer id");
     }
 }

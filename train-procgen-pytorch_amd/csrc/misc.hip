@@ -854,6 +854,7 @@ void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int 
     hipLaunchKernelGGL(colmax_partial_seg_kernel, dim3(G, st.n_seg), dim3(256), 0, stream, flat_pre, bf16, st, d, G, colmax_scratch);
     hipLaunchKernelGGL(fs_parts_seg_kernel, dim3(FS_PARTS, st.n_seg), dim3(256), 0, stream, (const float*)colmax_scratch, G, d, fs_parts);
 }
+int fs_metric_groups() { return FS_GROUPS; }                    // row groups launch_fs_metric leaves in its scratch
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st) {
     if (n <= 0) return;
     if (d % 8) abort();                                       // the flattened IMPALA feature map (2048)
@@ -896,6 +897,55 @@ __global__ __launch_bounds__(256) void fs_apply_kernel(void* G, int bf16, int d,
         unsigned short* p = (unsigned short*)G + o;
         *p = f2bf_g(__uint_as_float(((unsigned)*p) << 16) + g);
     } else ((float*)G)[o] += g;
+}
+// Multi-rank: the column maxima are those of the GLOBAL minibatch.  Every rank packs its own candidate per column
+// into one 64-bit key -- (bits of the local maximum) << 32 | (0xffffffff - global position of its first row attaining it) -- so that ONE
+// max-all-reduce yields the global maximum (non-negative floats order like their bit patterns) and, among equal maxima, the row that
+// comes first in the global minibatch (torch.max's choice in the single-process reference).  Key 0 = no positive value in the column.
+__global__ __launch_bounds__(256) void fs_keys_kernel(const float* colmax, const int* arg, const int32_t* gpos, int d, long long* keys, long long* keys_local) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d) return;
+    const int b = arg[j];
+    long long k = 0;
+    if (b != 0x7fffffff && colmax[j] > 0.f)
+        k = ((long long)__float_as_uint(colmax[j]) << 32) | (long long)(0xffffffffu - (unsigned)gpos[b]);
+    keys[j] = k; keys_local[j] = k;
+}
+// after the all-reduce: the winner of column j adds the gradient at its row; every rank takes the global maximum for the metric
+__global__ __launch_bounds__(256) void fs_apply_keys_kernel(void* G, int bf16, int d, const long long* keys, const long long* keys_local, const int* arg, float scale) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d) return;
+    const long long k = keys[j];
+    if (k == 0 || k != keys_local[j]) return;
+    const float m = __uint_as_float((unsigned)((unsigned long long)k >> 32));
+    const float t = tanhf(fabsf(m * 100.f)), g = scale * (1.f - t * t);
+    const long long o = (long long)arg[j] * d + j;
+    if (bf16) {
+        unsigned short* p = (unsigned short*)G + o;
+        *p = f2bf_g(__uint_as_float(((unsigned)*p) << 16) + g);
+    } else ((float*)G)[o] += g;
+}
+__global__ __launch_bounds__(1024) void fs_from_keys_kernel(const long long* keys, int d, float* fs_out) {      // mean_j tanh(|100 m_j|) of the global maxima
+    __shared__ double sb[16];
+    double s = 0.0;
+    for (int j = threadIdx.x; j < d; j += 1024) s += (double)tanhf(fabsf(__uint_as_float((unsigned)((unsigned long long)keys[j] >> 32)) * 100.f));
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sb[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double tot = 0.0; for (int k = 0; k < 16; ++k) tot += sb[k]; fs_out[0] = (float)(tot / d); }
+}
+// part: [G][d] partial column maxima of this rank's rows; gpos: global minibatch position of every local row (ascending)
+void launch_fs_keys(const void* x, int bf16, int n, int d, const float* part, int G, const int32_t* gpos, float* colmax, int* arg,
+                    long long* keys, long long* keys_local, hipStream_t st) {
+    hipLaunchKernelGGL(fs_colmax_final_kernel, dim3((d + 255) / 256), dim3(256), 0, st, part, G, d, colmax, arg);
+    if (n > 0) hipLaunchKernelGGL(fs_argfirst_kernel, dim3((d + 255) / 256, n < 64 ? n : 64), dim3(256), 0, st, x, bf16, n, d, (const float*)colmax, arg);
+    hipLaunchKernelGGL(fs_keys_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)colmax, (const int*)arg, gpos, d, keys, keys_local);
+}
+void launch_fs_apply_keys(void* Gd, int bf16, int d, const long long* keys, const long long* keys_local, const int* arg, float fs_coef, hipStream_t st) {
+    hipLaunchKernelGGL(fs_apply_keys_kernel, dim3((d + 255) / 256), dim3(256), 0, st, Gd, bf16, d, keys, keys_local, arg, fs_coef * 100.f / (float)d);
+}
+void launch_fs_from_keys(const long long* keys, int d, float* fs_out, hipStream_t st) {
+    hipLaunchKernelGGL(fs_from_keys_kernel, dim3(1), dim3(1024), 0, st, keys, d, fs_out);
 }
 // x: block3's output before the ReLU [n][d] (fp32 / bf16); part: [G][d] partial column maxima of relu(x); Gd: d loss / d x [n][d], updated in place
 void launch_fs_grad(const void* x, int bf16, int n, int d, const float* part, int G, void* Gd, float fs_coef, float* colmax, int* arg, hipStream_t st) {

@@ -15,16 +15,17 @@ def env_range(n_envs_global, rank, world):
     return rank * per, (rank + 1) * per
 
 
-def shard_indices(chunk, n_envs_global, rank, world):
+def shard_indices(chunk, n_envs_global, rank, world, with_positions=False):
     """Global flat indices i = t*E + e of one minibatch -> this rank's LOCAL flat indices
-    t*E_local + (e - e0), in the order they appear in the chunk."""
+    t*E_local + (e - e0), in the order they appear in the chunk (with_positions: also their positions in the chunk)."""
     chunk = np.asarray(chunk, dtype=np.int64)
     if world == 1:
-        return chunk
+        return (chunk, np.arange(len(chunk), dtype=np.int32)) if with_positions else chunk
     e0, e1 = env_range(n_envs_global, rank, world)
     t, e = chunk // n_envs_global, chunk % n_envs_global
     keep = (e >= e0) & (e < e1)
-    return t[keep] * (e1 - e0) + (e[keep] - e0)
+    local = t[keep] * (e1 - e0) + (e[keep] - e0)
+    return (local, np.nonzero(keep)[0].astype(np.int32)) if with_positions else local
 
 
 def merge_adv_stats(stats_list):
@@ -42,7 +43,8 @@ def merge_adv_stats(stats_list):
     return np.array([n, mean, m2], dtype=np.float64)
 
 
-def update_plan(chunks, rank, world, n_envs_global, grad_accumulation_steps, merge, stats_per_minibatch, max_batch, max_segments=16):
+def update_plan(chunks, rank, world, n_envs_global, grad_accumulation_steps, merge, stats_per_minibatch, max_batch, max_segments=16,
+                with_positions=False):
     """The host schedule of PPO.optimize (agents/ppo.py:155-177) for one rank, as a stream of operations -- pure index logic, no
     device: agents/ppo.py executes it on the engine, tests/test_dist_gloo.py on two CPU ranks.
 
@@ -55,7 +57,10 @@ def update_plan(chunks, rank, world, n_envs_global, grad_accumulation_steps, mer
       ("step",)                                  after every grad_accumulation_steps-th minibatch (the reference's `cnt % steps == 0`
                                                  with a float): gradient all-reduce + optimizer step
       ("log", n_minibatches)                     once at the end: reduce / read the per-minibatch records
+    with_positions (fs_coef != 0 on > 1 rank, not with `merge`): a "minibatch" op carries a fifth element, the positions of the local
+    samples in their global minibatch (the feature-sparsity term's tie rule needs the global order).
     """
+    assert not (merge and with_positions)
     assert not (merge and stats_per_minibatch)
     held, held_n, held_global, n_mb, cnt = [], 0, None, 0, 1
 
@@ -68,7 +73,10 @@ def update_plan(chunks, rank, world, n_envs_global, grad_accumulation_steps, mer
         return None
 
     for chunk in chunks:
-        local = shard_indices(chunk, n_envs_global, rank, world)
+        if with_positions:
+            local, pos = shard_indices(chunk, n_envs_global, rank, world, True)
+        else:
+            local = shard_indices(chunk, n_envs_global, rank, world)
         n_mb += 1
         if merge:
             if held_n + len(local) > max_batch or len(held) == max_segments or (held and len(chunk) != held_global):
@@ -79,7 +87,7 @@ def update_plan(chunks, rank, world, n_envs_global, grad_accumulation_steps, mer
             held_n += len(local)
             held_global = len(chunk)
         else:
-            yield ("minibatch", local, [len(local)], len(chunk))
+            yield ("minibatch", local, [len(local)], len(chunk), pos) if with_positions else ("minibatch", local, [len(local)], len(chunk))
             if stats_per_minibatch:
                 yield ("stats",)
         if cnt % grad_accumulation_steps == 0:
@@ -123,6 +131,11 @@ class Collective:
             self.td.all_reduce(tensor, op=self.td.ReduceOp.SUM, group=self.group)
         return tensor
 
+    def allreduce_max_(self, tensor):
+        if self.active:
+            self.td.all_reduce(tensor, op=self.td.ReduceOp.MAX, group=self.group)
+        return tensor
+
     def allgather_f64(self, vec):
         import torch
         if not self.active:
@@ -139,8 +152,8 @@ class DevicePointerTensor:
     """torch view of a raw device buffer owned by the engine (for RCCL all-reduce through
     torch.distributed): exposes __cuda_array_interface__ and lets torch.as_tensor alias it."""
 
-    def __init__(self, ptr, n_floats):
-        self.__cuda_array_interface__ = {"shape": (int(n_floats),), "typestr": "<f4", "data": (int(ptr), False),
+    def __init__(self, ptr, n_elems, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": (int(n_elems),), "typestr": typestr, "data": (int(ptr), False),
                                          "version": 2, "strides": None}
 
     def tensor(self, device_index=0):

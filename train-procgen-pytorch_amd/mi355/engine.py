@@ -13,7 +13,7 @@ _LIB = None
 
 ARCH_IMPALA, ARCH_MLP = 0, 1
 F_REW, F_DONE, F_VALUE, F_LOGP, F_ADV, F_RET, F_ACT = range(7)
-PTR_GRADS, PTR_LOSS_STATS, PTR_PARAMS, PTR_STATS_RING = 0, 1, 2, 3
+PTR_GRADS, PTR_LOSS_STATS, PTR_PARAMS, PTR_STATS_RING, PTR_FS_KEYS = 0, 1, 2, 3, 4
 LOSS_FIELDS = ("pi_loss", "value_loss", "entropy", "x_ent", "total", "fs", "marg", "_pad")
 
 
@@ -41,7 +41,7 @@ EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_fre
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
            "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_rollout_groups mi_rollout_submit mi_rollout_wait mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_minibatch_multi mi_optimizer_step mi_loss_log_read mi_device_ptr "
-           "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma mi_debug_read mi_debug_flags mi_comm_unique_id mi_comm_init mi_comm_destroy mi_allreduce_arm mi_allreduce_grads mi_allreduce_buffer mi_adv_normalize_global").split()
+           "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma mi_debug_read mi_debug_flags mi_comm_unique_id mi_comm_init mi_comm_destroy mi_allreduce_arm mi_allreduce_grads mi_allreduce_buffer mi_adv_normalize_global mi_minibatch_positions").split()
 
 
 def load_library():
@@ -461,6 +461,11 @@ class Engine:
             out = np.empty((n, hw, hw, ch), np.float32)
         self._chk(self.lib.mi_debug_read(self._ctx, C.c_int32(which), C.c_int32(n), _fp(out)))
         return out
+
+    def minibatch_positions(self, gpos):
+        """Global minibatch positions of the next minibatch()'s rows (fs_coef != 0 on several ranks, include/mi355ppo.h)."""
+        g = np.ascontiguousarray(gpos, dtype=np.int32)
+        self._chk(self.lib.mi_minibatch_positions(self._ctx, g.ctypes.data_as(C.c_void_p), C.c_int32(g.size)))
 
     def debug_flags(self, flags):
         self._chk(self.lib.mi_debug_flags(self._ctx, C.c_int32(flags)))
