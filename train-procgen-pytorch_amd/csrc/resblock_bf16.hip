@@ -26,6 +26,9 @@ __device__ __forceinline__ uint2 rb_pack(const float (&v)[4]) {
     return (uint2){mi_pk_bf16(v[0], v[1]), mi_pk_bf16(v[2], v[3])};
 }
 
+#ifndef RB_SWZ16
+#define RB_SWZ16 1       // 16-channel LDS images: chunk swap keyed on bit 2 of the column (0 = plain layout, for A/B timing)
+#endif
 #ifndef RB_S32
 #define RB_S32 48         // pixel stride (bf16 elements) of the 32-channel LDS tiles
 #endif
@@ -325,6 +328,12 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
     unsigned short* s_y = smem_h + C::X_ELEMS;
     unsigned short* s_w = s_y + C::Y_ELEMS;              // 4 banks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    // 16-channel images (32-byte pixels): the two 16-byte chunks of a pixel trade places where bit 2 of its haloed column is set.  The
+    // 8-byte epilogue stores of 16 pixels x one channel quad (ds_write_b64: 16 consecutive lanes per LDS cycle, 32 banks) hit every
+    // bank from 4 pixels (columns c, c+4, c+8, c+12) in the plain layout and from 2 with the swap; the 16-byte operand reads stay
+    // conflict-free (their 16-lane groups pair columns c and c+8 from different chunks, and the swap is the same for both).
+    constexpr bool SWZ = (C::C == 16) && RB_SWZ16;
+    const int eq = SWZ ? ((kq * 4) ^ ((((i + 1) >> 2) & 1) * 8)) : kq * 4;      // this lane's channel quad inside its pixel (tile columns start at 0 / 16)
     for (int e = tid; e < C::W_ELEMS / 8; e += C::NT)
 #pragma unroll
         for (int l = 0; l < 4; ++l) ((uint4*)(s_w + l * C::W_ELEMS))[e] = ((const uint4*)a.bank[l])[e];
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
     for (int m = 0; m < C::NK; ++m) {
         int tap, chunk;
         if (C::C == 32) { tap = m; chunk = kq; } else { tap = 2 * m + (kq >> 1); chunk = kq & 1; if (tap > 8) tap = 8; }
+        if (SWZ) chunk ^= ((i + tap % 3) >> 2) & 1;        // column of this lane's pixel under the tap (tiles start at columns 0 / 16)
         koff[m] = ((tap / 3) * C::P + (tap % 3)) * C::S + chunk * 8;
     }
     const int nwork = (a.n + C::NIMG - 1) / C::NIMG;
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
             if (e < C::NSRC) {
                 const int c8 = e % C::C8, px = (e / C::C8) % C::HW, rr = e / (C::C8 * C::HW);
                 const uint4 v = regs[k];
-                *(uint4*)(s_x + (rr * C::P + px + 1) * C::S + c8 * 8) = v;      // RAW: conv1 applies the ReLU on its operand reads, the skip reads it back
+                *(uint4*)(s_x + (rr * C::P + px + 1) * C::S + (SWZ ? (c8 ^ (((px + 1) >> 2) & 1)) : c8) * 8) = v;      // RAW: conv1 applies the ReLU on its operand reads, the skip reads it back
             }
         }
         __syncthreads();
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
                         for (int r = 0; r < 4; ++r) v[r] = acc[mt][nb][r] + bq[r];
                         const uint2 raw = rb_pack(v);
                         if (a_out && on) *(uint2*)(a_out + base + poff[mt] + nb * 16) = raw;
-                        *(uint2*)(s_y + abase[mt] + CENTER + kq * 4 + nb * 16) = (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};
+                        *(uint2*)(s_y + abase[mt] + CENTER + eq + nb * 16) = (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};
                     }
                 }
             }
@@ -420,12 +430,12 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
                     for (int nb = 0; nb < C::NB; ++nb) {
                         float v[4];
                         const f32x4 bq = *(const f32x4*)(s_b + (2 * st + 1) * C::C + nb * 16 + kq * 4);
-                        const uint2 sk = *(const uint2*)(s_x + abase[mt] + CENTER + kq * 4 + nb * 16);      // skip connection: this stage's raw input
+                        const uint2 sk = *(const uint2*)(s_x + abase[mt] + CENTER + eq + nb * 16);      // skip connection: this stage's raw input
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = acc[mt][nb][r] + bq[r] + rb_lane(sk, r);
                         const uint2 raw = rb_pack(v);
                         if (y_out && on) *(uint2*)(y_out + base + poff[mt] + nb * 16) = raw;
-                        if (st == 0) *(uint2*)(s_x + abase[mt] + CENTER + kq * 4 + nb * 16) = raw;      // res2's input (raw: conv operand ReLU'd on read, skip as is)
+                        if (st == 0) *(uint2*)(s_x + abase[mt] + CENTER + eq + nb * 16) = raw;      // res2's input (raw: conv operand ReLU'd on read, skip as is)
                     }
                 }
             }
