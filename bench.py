@@ -207,7 +207,7 @@ def main():
                     "(minibatches of mini_batch_size/R, R-fold gradient accumulation, no collectives)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="diagnostic: run the N-rank code path (sharding, merged accumulation, "
                     "gradient / statistics all-reduce, barriers) with every rank on GPU 0 and the gloo backend; the number it prints is not a result")
-    ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic: mi_debug_flags bits (1: unfused rollout tail, 2: no update side stream)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic: mi_debug_flags bits (1: unfused rollout tail, 4: frames always uploaded by DMA copy, never pulled by a kernel)")
     ap.add_argument("--no-h2d", action="store_true", help="diagnostic: policy steps read frames already resident in HBM (no per-step upload); "
                     "the default uploads every step's E frames from pinned host memory inside the timed region, as the real loop must")
     ap.add_argument("--rollout-groups", type=int, default=0, help="env groups of the pipelined rollout (0 = auto: 4 when n_envs >= 128 divides, else 2; "

@@ -227,7 +227,8 @@ int mi_selftest_mfma(mi_ctx* ctx, float* max_err);
  * Lets a parity test run the oracle's backward pass on the ENGINE's forward tensors (teacher forcing, tests/test_gpu_bf16.py). */
 int mi_debug_read(mi_ctx* ctx, int32_t which, int32_t n, float* out);
 /* bit 0 set: rollout-sized bf16 inference passes use the separate block-2 / block-3 kernels instead of the fused launch
- * (rollout_bf16.hip) -- the A side of the bit-equality test of the two paths */
+ * (rollout_bf16.hip) -- the A side of the bit-equality test of the two paths;
+ * bit 2 set: a group's frames always go up by DMA copy, never pulled by a kernel (A/B timing) */
 int mi_debug_flags(mi_ctx* ctx, int32_t flags);
 
 #ifdef __cplusplus

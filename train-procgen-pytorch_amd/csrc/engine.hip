@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include <atomic>
 #include <condition_variable>
@@ -89,7 +90,7 @@ struct Profiler {
 struct mi_ctx;
 static void prof_harvest(mi_ctx* c);
 // one step of one env group, as the submitting thread hands it to the group's worker
-struct GroupJob { int t; const void* frames; size_t bytes; bool have_rd, last; const float* u; unsigned long long seed; unsigned ticket; };
+struct GroupJob { int t; const void* frames; size_t bytes; bool pull; bool have_rd, last; const float* u; unsigned long long seed; unsigned ticket; };
 struct GroupWorker {
     std::thread th; std::mutex mu; std::condition_variable cv;
     std::atomic<unsigned> posted{0}, done{0}; std::atomic<bool> sleeping{false}, quit{false};
@@ -157,6 +158,7 @@ struct mi_ctx {
     int n_groups; hipStream_t main_stream, gs[MAX_GROUPS]; hipEvent_t ev_fork[MAX_GROUPS], ev_join[MAX_GROUPS];
     bool g_forked[MAX_GROUPS], g_busy[MAX_GROUPS], g_last[MAX_GROUPS], g_dirty[MAX_GROUPS]; unsigned g_ticket[MAX_GROUPS]; bool groups_live;
     struct GroupWorker* gw[MAX_GROUPS];      // one host thread per group issues that group's copies + launches (a step is ~9 API calls = ~30 us of host time)
+    std::unordered_map<const void*, bool> pull_ok; bool no_pull;      // frame buffers a kernel may read (mi_debug_flags bit 2: always DMA)
     bool rollout_tail;          // bf16 inference passes of <= 256 samples run blocks 2 + 3 as one launch (mi_debug_flags bit 0 clears it: A/B tests)
     float *fs_colmax, fs_grad_coef; int *fs_arg, fs_G;      // feature-sparsity gradient (fs_coef != 0): column maxima / first arg-max rows of the minibatch
     // ... on more than one rank (multirank mode 1): per-column candidates for the max-all-reduce (MI_PTR_FS_KEYS), this rank's own copy, and
@@ -386,7 +388,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(dalloc(&c->d_done_ctr, (size_t)16)); HIPC(hipHostMalloc((void**)&c->h_flag, 64, hflags)); memset(c->h_flag, 0, 64); c->roll_ticket = 0;
     HIPC(dalloc(&c->s_act, (size_t)E)); HIPC(dalloc(&c->s_logp, (size_t)E)); HIPC(dalloc(&c->s_val, (size_t)E)); c->staged_valid = false;
     for (int k = 0; k < mi_ctx::IDX_RING; ++k) {
-        HIPC(hipHostMalloc((void**)&c->h_idx_ring[k], (size_t)NB * sizeof(int32_t)));
+        HIPC(hipHostMalloc((void**)&c->h_idx_ring[k], (size_t)NB * sizeof(int32_t), hflags));      // coherent + mapped: a kernel reads it
         HIPC(hipEventCreateWithFlags(&c->idx_ev[k], hipEventDisableTiming));
         c->idx_used[k] = false;
     }
@@ -396,7 +398,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
     c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stream = nullptr; c->ev_ar_ready = c->ev_ar_done = nullptr;
     c->ar_armed = c->ar_issued = c->ar_inflight = false; c->adv_all = nullptr;
-    c->fs_grad_coef = 0.f; c->fs_G = 0; c->rollout_tail = true;
+    c->fs_grad_coef = 0.f; c->fs_G = 0; c->rollout_tail = true; c->no_pull = false;
     if (cfg->arch != MI_ARCH_IMPALA) { c->fs_colmax = nullptr; c->fs_arg = nullptr; c->fs_keys = c->fs_keys_local = nullptr; c->d_gpos = nullptr; c->h_gpos = nullptr; }
     c->gpos_n = -1; c->fs_global_pending = c->fs_global_apply = false;
     c->n_groups = 1; c->groups_live = false; c->main_stream = c->stream;
@@ -1084,7 +1086,13 @@ static int group_issue(mi_ctx* c, int g, const GroupJob& j) {
     const int E = c->E, ng = E / c->n_groups, e0 = g * ng;
     hipStream_t st = tl_stream;
     char* ring = c->frames ? (char*)c->frames : (char*)c->obsf;
-    if (j.frames) HIPC(hipMemcpyAsync(ring + ((size_t)j.t * E + e0) * c->obs_bytes_per_env, j.frames, j.bytes, hipMemcpyHostToDevice, st));
+    if (j.frames) {
+        char* dst = ring + ((size_t)j.t * E + e0) * c->obs_bytes_per_env;
+        // page-locked, device-visible frames are PULLED by a kernel on the group's stream: a DMA copy in front of the first conv costs the
+        // hand-over from the compute queue to the copy engine and back on top of the transfer (misc.hip pull_i32_kernel)
+        if (j.pull) launch_pull_bytes(j.frames, dst, j.bytes, st);
+        else HIPC(hipMemcpyAsync(dst, j.frames, j.bytes, hipMemcpyHostToDevice, st));
+    }
     float* h_rd = c->h_rd + 2 * e0;      // this group's {rew[ng], done[ng]} (pinned, device-visible), filled by the submitting thread
     if (j.have_rd && c->gru_on) HIPC(hipMemcpyAsync(c->d_done + e0, h_rd + ng, (size_t)ng * 4, hipMemcpyHostToDevice, st));
     const float* du = nullptr;
@@ -1162,7 +1170,22 @@ int mi_rollout_submit(mi_ctx* c, int32_t t, int32_t g, const void* frames, size_
     const bool have_rd = rew_prev != nullptr;
     if (have_rd) { float* h_rd = c->h_rd + 2 * e0; memcpy(h_rd, rew_prev, (size_t)ng * 4); memcpy(h_rd + ng, done_prev, (size_t)ng * 4); }
     const bool last = (t == c->T);
-    w->job = GroupJob{t, frames, bytes, have_rd, last, u, seed, ++c->g_ticket[g]};
+    bool pull = false;
+    // Pull only what is latency-bound: measured per policy step, E = 64 in 2 groups (393 KB each) 73-76 us pulled vs 84-86 us copied,
+    // E = 256 in 4 groups (786 KB each, four pulls competing) 121-135 vs 108-112 us -- shader reads of host memory move fewer bytes per
+    // second than the copy engine, so above 512 KB the DMA's hand-over is the smaller price.
+    if (frames && !c->no_pull && bytes <= (512u << 10) && (bytes & 15) == 0 && ((uintptr_t)frames & 15) == 0) {      // device-visible pinned memory? (asked once per buffer)
+        auto it = c->pull_ok.find(frames);
+        if (it == c->pull_ok.end()) {
+            hipPointerAttribute_t at{};
+            const bool ok = hipPointerGetAttributes(&at, frames) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer == frames;
+            if (!ok) (void)hipGetLastError();
+            if (c->pull_ok.size() > 64) c->pull_ok.clear();
+            it = c->pull_ok.emplace(frames, ok).first;
+        }
+        pull = it->second;
+    }
+    w->job = GroupJob{t, frames, bytes, pull, have_rd, last, u, seed, ++c->g_ticket[g]};
     w->posted.fetch_add(1, std::memory_order_seq_cst);
     if (w->sleeping.load()) { { std::lock_guard<std::mutex> lk(w->mu); } w->cv.notify_one(); }
     c->g_busy[g] = true; c->g_last[g] = last;
@@ -1397,7 +1420,7 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
         if (c->idx_used[slot]) HIPC(hipEventSynchronize(c->idx_ev[slot]));     // the DMA that read this slot is done
         int32_t* h = c->h_idx_ring[slot];
         for (int k = 0; k < n; ++k) h[k] = (int32_t)idx[k];
-        HIPC(hipMemcpyAsync(c->d_idx, h, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        launch_pull_i32(h, c->d_idx, n, c->stream);              // (not hipMemcpyAsync: see pull_i32_kernel)
         HIPC(hipEventRecord(c->idx_ev[slot], c->stream));
         c->idx_used[slot] = true;
     }
@@ -1840,7 +1863,7 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
 }
 
 // bit 0: run rollout-sized bf16 inference passes on the separate block-2 / block-3 kernels instead of the fused launch (parity A/B)
-int mi_debug_flags(mi_ctx* c, int32_t flags) { ARG(c, "null"); JOIN(c); c->rollout_tail = !(flags & 1); return 0; }
+int mi_debug_flags(mi_ctx* c, int32_t flags) { ARG(c, "null"); JOIN(c); c->rollout_tail = !(flags & 1); c->no_pull = (flags & 4) != 0; return 0; }
 
 // Read back what the last training-mode pass (mi_minibatch) left in the activation buffers, as fp32 NHWC: which = 8 * block + k with
 // k = 0 P0 (pooled map), 1 A1, 2 P1, 3 A2, 4 P2 (res1.conv1 out, res1 out, res2.conv1 out, block out), 5 the max-pool arg-max bytes

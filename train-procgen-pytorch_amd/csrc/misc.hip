@@ -1335,6 +1335,35 @@ void launch_sumsq_partials(const float* g, long long n, double* part /* 128 doub
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(128), dim3(256), 0, st, g, n, part);
 }
 
+// A minibatch's indices, pulled from the pinned host ring by a kernel on the compute stream: hipMemcpyAsync in that place (32 KB between
+// one minibatch's optimizer step and the next one's first conv) left the chip idle for ~23 us per minibatch -- the compute queue hands
+// over to the copy engine and back (rocprofv3 kernel trace: the only gap of the update phase); moving the copy to a stream of its own
+// only traded it for the event wait.  Eight workgroups reading 16 bytes per lane over PCIe take ~4 us, in stream order, no hand-over.
+__global__ __launch_bounds__(256) void pull_i32_kernel(const int32_t* __restrict__ host_src, int32_t* __restrict__ dst, int n) {
+    const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (k + 4 <= n) *(int4*)(dst + k) = *(const int4*)(host_src + k);
+    else for (int j = k; j < n; ++j) dst[j] = host_src[j];
+}
+// The same for a group's frames (E/G x 12 KB per policy step): workgroups of 256 lanes, four 16-byte PCIe reads in flight per lane
+typedef unsigned pull_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void pull_bytes_kernel(const pull_u32x4* __restrict__ host_src, pull_u32x4* __restrict__ dst, long long n16) {
+    const long long k0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+    pull_u32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { long long k = k0 + j * 256; if (k >= n16) k = n16 - 1; v[j] = __builtin_nontemporal_load(host_src + k); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const long long k = k0 + j * 256; if (k < n16) dst[k] = v[j]; }
+}
+void launch_pull_bytes(const void* host_src, void* dst, size_t bytes /* multiple of 16 */, hipStream_t st) {
+    const long long n16 = (long long)(bytes / 16);
+    if (n16 <= 0) return;
+    hipLaunchKernelGGL(pull_bytes_kernel, dim3((unsigned)((n16 + 1023) / 1024)), dim3(256), 0, st, (const pull_u32x4*)host_src, (pull_u32x4*)dst, n16);
+}
+void launch_pull_i32(const int32_t* host_src, int32_t* dst, int n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(pull_i32_kernel, dim3((n + 1023) / 1024), dim3(256), 0, st, host_src, dst, n);
+}
+
 // ------------------------------------------------------------------------------------------ GRU cell (rollout only)
 // nn.GRU single step (common/model.py:219-225): gi = W_ih x + b_ih, gh = W_hh (h*mask) + b_hh come from the GEMM;
 // r = s(gi_r+gh_r), z = s(gi_z+gh_z), n = tanh(gi_n + r*gh_n), h' = (1-z)*n + z*h.
