@@ -99,7 +99,10 @@ int mi_rollout_step(mi_ctx* ctx, int32_t t, const float* rew_prev, const float* 
  *      previous step's reward / done of the group (rew_prev / done_prev: E/G floats each, may be NULL at t == 0); it returns at once.
  *      mi_rollout_wait(g, ...) blocks until that step's results (E/G entries each) are on the host.  One step per group in flight.
  *      Sampling uses the Philox counters t*E + e of mi_rollout_step: grouped and ungrouped rollouts draw the same actions.
- *      Any other entry point first orders the context's main stream behind all group streams. */
+ *      Any other entry point first orders the context's main stream behind all group streams.
+ *      The groups' uploads take turns on the PCIe link (each reserves bytes / rate from the end of the previous reservation; environment
+ *      variable MI355_COPY_GBPS, default 40, 0 = off): issued together they share the link, finish together and keep the chains in
+ *      lock-step.  Uploads of at most 512 KB from device-visible pinned memory are pulled by a kernel instead of the copy engine. */
 int mi_rollout_groups(mi_ctx* ctx, int32_t n_groups);
 int mi_rollout_submit(mi_ctx* ctx, int32_t t, int32_t group, const void* frames, size_t bytes, const float* rew_prev,
                       const float* done_prev, uint64_t seed, const float* u);

@@ -18,6 +18,7 @@
 #include <unordered_map>
 #include <vector>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -158,6 +159,7 @@ struct mi_ctx {
     int n_groups; hipStream_t main_stream, gs[MAX_GROUPS]; hipEvent_t ev_fork[MAX_GROUPS], ev_join[MAX_GROUPS];
     bool g_forked[MAX_GROUPS], g_busy[MAX_GROUPS], g_last[MAX_GROUPS], g_dirty[MAX_GROUPS]; unsigned g_ticket[MAX_GROUPS]; bool groups_live;
     struct GroupWorker* gw[MAX_GROUPS];      // one host thread per group issues that group's copies + launches (a step is ~9 API calls = ~30 us of host time)
+    std::atomic<int64_t> copy_slot_ns{0}; double copy_rate_bytes_per_us;      // uploads of the env groups take turns on the PCIe link (group_issue)
     std::unordered_map<const void*, bool> pull_ok; bool no_pull;      // frame buffers a kernel may read (mi_debug_flags bit 2: always DMA)
     bool rollout_tail;          // bf16 inference passes of <= 256 samples run blocks 2 + 3 as one launch (mi_debug_flags bit 0 clears it: A/B tests)
     float *fs_colmax, fs_grad_coef; int *fs_arg, fs_G;      // feature-sparsity gradient (fs_coef != 0): column maxima / first arg-max rows of the minibatch
@@ -398,7 +400,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
     c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stream = nullptr; c->ev_ar_ready = c->ev_ar_done = nullptr;
     c->ar_armed = c->ar_issued = c->ar_inflight = false; c->adv_all = nullptr;
-    c->fs_grad_coef = 0.f; c->fs_G = 0; c->rollout_tail = true; c->no_pull = false;
+    c->fs_grad_coef = 0.f; c->fs_G = 0; c->rollout_tail = true; c->no_pull = false; c->copy_rate_bytes_per_us = getenv("MI355_COPY_GBPS") ? atof(getenv("MI355_COPY_GBPS")) * 1000.0 : 40000.0;
     if (cfg->arch != MI_ARCH_IMPALA) { c->fs_colmax = nullptr; c->fs_arg = nullptr; c->fs_keys = c->fs_keys_local = nullptr; c->d_gpos = nullptr; c->h_gpos = nullptr; }
     c->gpos_n = -1; c->fs_global_pending = c->fs_global_apply = false;
     c->n_groups = 1; c->groups_live = false; c->main_stream = c->stream;
@@ -1088,6 +1090,17 @@ static int group_issue(mi_ctx* c, int g, const GroupJob& j) {
     char* ring = c->frames ? (char*)c->frames : (char*)c->obsf;
     if (j.frames) {
         char* dst = ring + ((size_t)j.t * E + e0) * c->obs_bytes_per_env;
+        // One upload at a time.  Uploads of several groups issued together share the PCIe link and all finish late and TOGETHER: the
+        // groups' chains then stay in lock-step and every step pays the shared-link copy time (two stable regimes were measured at
+        // E = 256, G = 4: 107 and 135-138 us per policy step).  Each upload reserves the link for bytes / rate from the moment the previous
+        // reservation ends (a few us of spinning on the worker thread, only when groups bunch), which puts the chains out of step again.
+        if (c->copy_rate_bytes_per_us > 0) {
+            const int64_t gap = (int64_t)((double)j.bytes * 1000.0 / c->copy_rate_bytes_per_us);
+            const auto clk = [] { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            int64_t slot = c->copy_slot_ns.load(), start;
+            do { const int64_t now = clk(); start = now > slot ? now : slot; } while (!c->copy_slot_ns.compare_exchange_weak(slot, start + gap));
+            while (clk() < start) __builtin_ia32_pause();
+        }
         // page-locked, device-visible frames are PULLED by a kernel on the group's stream: a DMA copy in front of the first conv costs the
         // hand-over from the compute queue to the copy engine and back on top of the transfer (misc.hip pull_i32_kernel)
         if (j.pull) launch_pull_bytes(j.frames, dst, j.bytes, st);
