@@ -267,6 +267,7 @@ using RB_16_32 = RbCfg<16, 32, RB16_CFG>;   // whole image (85 KB: one workgroup
 using RB_32_16 = RbCfg<32, 16, 16, 1, RB32_NT>; // whole image, 101 KB: ONE workgroup per CU, so it is 512 threads (2 waves per SIMD); 8-row
                                             // tiles (77 KB, 2 x 256 threads per CU, 25 % halo recompute) measured slower: 7.7 vs 6.3 ms
 using RB_32_8  = RbCfg<32,  8,  8, 2>;      // 70 KB: 2 per CU
+using RB_32_8P = RbCfg<32,  8,  8, 4, 512>; // pair kernel (four banks): 155 KB, one 512-thread workgroup per CU = 2 waves per SIMD (2 images x 256 threads: 116 KB, ONE wave per SIMD)
 using RB_32_8S = RbCfg<32,  8,  8, 1>;      // rollout-sized batches: one image per workgroup (more workgroups, less serial work each)
 
 template <class C, bool BWD = false>
@@ -1216,7 +1217,7 @@ void launch_resblock_pair_bf16(ConvShape s, const void* x, const float* const* b
     switch (s) {
         case CS_16_16_32: launch_rbp_t<RB_16_32>(a, st); break;
         case CS_32_32_16: launch_rbp_t<RB_32_16>(a, st); break;
-        case CS_32_32_8:  if (n <= 1024) launch_rbp_t<RB_32_8S>(a, st); else launch_rbp_t<RB_32_8>(a, st); break;
+        case CS_32_32_8:  if (n <= 1024) launch_rbp_t<RB_32_8S>(a, st); else launch_rbp_t<RB_32_8P>(a, st); break;
         default: break;
     }
 }
