@@ -738,6 +738,11 @@ static void linear_wgrad(mi_ctx* c, const float* dY, const float* X, int relu_x,
 }
 
 static void net_heads(mi_ctx* c, int n, int soff = 0) {
+    if (c->H == 256 && c->A + 1 <= 16 && n >= 1024) {      // update-sized batches: dedicated kernel (misc.hip heads_fwd_kernel)
+        ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * c->H + (double)n * (c->A + 1) + (double)c->H * (c->A + 1)), 2.0 * n * c->H * (c->A + 1));
+        launch_heads_fwd(c->feat + (size_t)soff * c->H, c->params + c->wh_off, c->params + c->bh_off, c->hout + (size_t)soff * (c->A + 1), n, c->A + 1, CUR(c));
+        return;
+    }
     linear_fwd(c, c->feat + (size_t)soff * c->H, 0, c->params + c->wh_off, c->params + c->bh_off, c->hout + (size_t)soff * (c->A + 1), n, c->H, c->A + 1, 0);
 }
 // h' = GRU(feat, h_state * (1 - done)); feat <- h' ; h_state <- h'   (n == E rows)

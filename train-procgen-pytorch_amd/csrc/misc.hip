@@ -436,6 +436,42 @@ void launch_colsum_acc(const float* dY, int M, int N, int ld, float* db, float* 
     launch_reduce_slabs(col_ws, gy * 4, N, db, N, nullptr, 0, st);
 }
 
+// ------------------------------------------------------------------------------------------ heads forward (training-sized batches)
+// hout[s][o] = feat[s] . Wh[o] + bh[o] for the (A+1) <= 16 head outputs, H == 256 (policy.py:74-80).  The generic GEMM ran this
+// 8192 x 16 x 256 product as 16-wide tiles of a 64-wide kernel plus a split-K pass (19 us); here 16 rows and the head matrix go
+// through LDS and thread (row, output) owns one dot product, summed in the order of heads_sample_kernel -- the rollout's logits and
+// the update's logits of one observation under one set of weights are the same bits.
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ Wh, const float* __restrict__ bh,
+                                                        float* __restrict__ hout, int n, int O) {
+    __shared__ __attribute__((aligned(16))) float s_f[16 * 260];
+    __shared__ __attribute__((aligned(16))) float s_w[16 * 260];
+    const int tid = threadIdx.x, e0 = blockIdx.x * 16, el = tid >> 4, o = tid & 15;
+    f32x4 rf[4], rw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = tid + j * 256, r = k >> 6, kk = (k & 63) * 4;
+        const int rr = e0 + r < n ? e0 + r : n - 1;
+        rf[j] = *(const f32x4*)(feat + (long long)rr * 256 + kk);
+        rw[j] = *(const f32x4*)(Wh + (long long)(r < O ? r : O - 1) * 256 + kk);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int k = tid + j * 256; *(f32x4*)(s_f + (k >> 6) * 260 + (k & 63) * 4) = rf[j]; *(f32x4*)(s_w + (k >> 6) * 260 + (k & 63) * 4) = rw[j]; }
+    __syncthreads();
+    const float* w = s_w + o * 260;
+    const float* f = s_f + el * 260;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 256; k += 4) {
+        const f32x4 fv = *(const f32x4*)(f + k), ww = *(const f32x4*)(w + k);
+        acc += fv.x * ww.x + fv.y * ww.y + fv.z * ww.z + fv.w * ww.w;
+    }
+    if (o < O && e0 + el < n) hout[(long long)(e0 + el) * O + o] = acc + bh[o];
+}
+void launch_heads_fwd(const float* feat, const float* Wh, const float* bh, float* hout, int n, int O, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3((n + 15) / 16), dim3(256), 0, st, feat, Wh, bh, hout, n, O);
+}
+
 // ------------------------------------------------------------------------------------------ heads backward in one launch
 // The policy / value heads are one 256 x (A+1) linear layer (policy.py:74-80): their data gradient, weight gradient and bias gradient
 // used to be two GEMM launches (each too small to fill a matrix-core tile grid), a split-K reduce and a two-stage column sum -- five
@@ -454,12 +490,13 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
     for (int o = 0; o < 16; ++o) { w[o] = (o < O && k < H) ? Wh[(long long)o * H + k] : 0.f; gw[o] = 0.f; }
     const int kk = k < H ? k : H - 1;
     int s = r0;
-    for (; s + 4 <= r1; s += 4) {                         // 4 rows in flight
-        float f[4], d[4];
+    constexpr int RF = 8;                                  // rows in flight (a workgroup's rows are a chain of load round trips otherwise)
+    for (; s + RF <= r1; s += RF) {
+        float f[RF], d[RF];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) f[q] = feat[(long long)(s + q) * H + kk];
+        for (int q = 0; q < RF; ++q) f[q] = feat[(long long)(s + q) * H + kk];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RF; ++q) {
             hb_const_f32p dy = (hb_const_f32p)(dY + (long long)(s + q) * O);
             float acc = 0.f;
 #pragma unroll
@@ -469,7 +506,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
         }
         if (k < H) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dfeat[(long long)(s + q) * H + k] = d[q];
+            for (int q = 0; q < RF; ++q) dfeat[(long long)(s + q) * H + k] = d[q];
         }
     }
     for (; s < r1; ++s) {
@@ -488,11 +525,11 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
     }
     if (k < O) sl[(long long)O * H + k] = gb;
 }
-// gW[O][H] += dY^T feat ; gb[O] += colsum(dY) ; dfeat = (dY W) * (feat > 0 if relu_mask).  ws: >= 256 * (O*H + O) floats.
+// gW[O][H] += dY^T feat ; gb[O] += colsum(dY) ; dfeat = (dY W) * (feat > 0 if relu_mask).  ws: >= 512 * (O*H + O) floats.
 void launch_heads_bwd(const float* dY, const float* feat, const float* Wh, int relu_mask, float* dfeat, float* gW, float* gb, float* ws,
                       int n, int H, int O, hipStream_t st) {
     if (n <= 0) return;
-    int grid = (n + 31) / 32; grid = grid > 256 ? 256 : grid;          // >= 32 rows per workgroup at the training sizes
+    int grid = (n + 15) / 16; grid = grid > 512 ? 512 : grid;          // 16 rows per workgroup at the training sizes: two steps of 8 rows, two workgroups per CU
     hipLaunchKernelGGL(heads_bwd_kernel, dim3(grid), dim3(256), 0, st, dY, feat, Wh, relu_mask, dfeat, ws, n, H, O);
     launch_reduce_slabs(ws, grid, O * H + O, gW, O * H, gb, O, st);
 }
