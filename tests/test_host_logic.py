@@ -84,6 +84,21 @@ def test_layout_roundtrip_and_order():
     assert sum(int(np.prod(s)) for s in layout.mlp_param_shapes(2, 9, 4, 256, 64).values()) == 150787
 
 
+def test_single_threaded_permutation_draw_is_torch_randperm():
+    """The permutation is drawn with one intra-op thread (3 ms of idle GPU per optimize() otherwise): same numbers as torch.randperm at
+    the production size, the generator advanced identically, the caller's thread count put back."""
+    from common.storage import _randperm_serial
+    k = torch.get_num_threads()
+    for n in (7, 4096, 65536):
+        torch.manual_seed(123 + n)
+        want = torch.randperm(n).numpy()
+        after_want = torch.rand(1).item()
+        torch.manual_seed(123 + n)
+        got = _randperm_serial(n)
+        assert np.array_equal(got, want) and torch.rand(1).item() == after_want
+    assert torch.get_num_threads() == k
+
+
 def test_index_streams_bit_exact_with_reference():
     """Storage.minibatch_index_stream consumes the torch CPU generator exactly like the reference's
     BatchSampler(SubsetRandomSampler) / randperm(E) (golden G2)."""
