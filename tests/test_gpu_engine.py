@@ -393,11 +393,13 @@ def test_policy_step_sampling():
     eng.close()
 
 
-@pytest.mark.parametrize("arch,precision,groups", [("impala", "bf16", 2), ("impala", "fp32", 4), ("mlp", "fp32", 2)])
-def test_pipelined_rollout_groups_equal_serial_steps(arch, precision, groups):
+@pytest.mark.parametrize("arch,precision,groups,dma", [("impala", "bf16", 2, False), ("impala", "bf16", 2, True), ("impala", "fp32", 4, False),
+                                                        ("mlp", "fp32", 2, False)])
+def test_pipelined_rollout_groups_equal_serial_steps(arch, precision, groups, dma):
     """mi_rollout_submit / mi_rollout_wait over G env groups (own streams, own rows of the activation buffers, frames uploaded by the
     submit) leave the ring and return the numbers of the serial mi_put_obs + mi_rollout_step loop: bit-equal actions / log-probs /
-    values / rewards / dones / frames (same kernels on the same rows; Philox counters t*E + e in both)."""
+    values / rewards / dones / frames (same kernels on the same rows; Philox counters t*E + e in both).  Group uploads this small are
+    pulled from the pinned buffer by a kernel; dma=True (mi_debug_flags bit 2) sends them through the copy engine like the large ones."""
     from mi355 import engine as M, layout
     from mi355.engine import Engine
     T, E, A = 3, 32, (15 if arch == "impala" else 2)
@@ -430,6 +432,8 @@ def test_pipelined_rollout_groups_equal_serial_steps(arch, precision, groups):
 
     pip = mk(); pip.set_params(flat)
     pip.rollout_groups(groups)
+    if dma:
+        pip.debug_flags(4)
     ng = E // groups
     stage = [[pip.pinned(obs[0, :ng].shape, obs.dtype) for _ in range(2)] for _ in range(groups)]
     outs = []
