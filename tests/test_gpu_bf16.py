@@ -140,6 +140,23 @@ def test_block_conv_pool_fused_bf16(eng, cin, cout, hw, n):
         assert np.array_equal(eng.op_conv3x3(7, cin, cout, hw, w.numpy(), inp=x_dev, bias=b.numpy(), dout=nhwc(dy)), gx)
 
 
+@pytest.mark.parametrize("cin,cout,hw", [(16, 32, 32), (32, 32, 16)])
+def test_block_conv_pool_rolling_rows_equal_the_item_kernel(eng, cin, cout, hw):
+    """Update-sized launches (n >= 1024) of conv + max pool walk down whole images with the last key row carried over in LDS
+    (conv_pool_fwd_roll_bf16_kernel); smaller launches take 4-pooled-row items with one conv row recomputed.  Same arithmetic per conv
+    output and pooling window: 1030 images in one launch == the same images in two launches of 515, bit for bit -- the pooled map, and
+    (through the data gradient taken from a pooled gradient and the forward's arg-max bytes) the arg-max routes as well."""
+    n = 1030
+    w, b, x_dev, _ = _inputs(cin, cout, hw, n, 31)
+    whole = eng.op_conv3x3(3, cin, cout, hw, w.numpy(), inp=x_dev, bias=b.numpy())
+    halves = np.concatenate([eng.op_conv3x3(3, cin, cout, hw, w.numpy(), inp=x_dev[k:k + 515], bias=b.numpy()) for k in (0, 515)])
+    assert np.array_equal(whole, halves) and np.abs(whole).max() > 0
+    dy = nhwc(r16(torch.randn(n, cout, hw // 2, hw // 2, generator=torch.Generator().manual_seed(32))))
+    gx = eng.op_conv3x3(5, cin, cout, hw, w.numpy(), inp=x_dev, bias=b.numpy(), dout=dy)
+    gx2 = np.concatenate([eng.op_conv3x3(5, cin, cout, hw, w.numpy(), inp=x_dev[k:k + 515], bias=b.numpy(), dout=dy[k:k + 515]) for k in (0, 515)])
+    assert np.array_equal(gx, gx2)
+
+
 @pytest.mark.parametrize("ch,hw", [(16, 32), (32, 16), (32, 8)])
 @pytest.mark.parametrize("n", [1, 6])
 def test_fused_residual_block_bf16(eng, ch, hw, n):
