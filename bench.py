@@ -207,6 +207,8 @@ def main():
                     "(minibatches of mini_batch_size/R, R-fold gradient accumulation, no collectives)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="diagnostic: run the N-rank code path (sharding, merged accumulation, "
                     "gradient / statistics all-reduce, barriers) with every rank on GPU 0 and the gloo backend; the number it prints is not a result")
+    ap.add_argument("--no-merge", action="store_true", help="diagnostic (with --rank-share R): the R accumulated passes of a minibatch run one by one "
+                    "instead of merged into one pass -- what splitting a minibatch into cache-sized pieces would cost / gain")
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic: mi_debug_flags bits (1: unfused rollout tail, 4: frames always uploaded by DMA copy, never pulled by a kernel)")
     ap.add_argument("--no-h2d", action="store_true", help="diagnostic: policy steps read frames already resident in HBM (no per-step upload); "
                     "the default uploads every step's E frames from pinned host memory inside the timed region, as the real loop must")
@@ -249,6 +251,8 @@ def main():
         episode_reward_buffer = [0.0]
         logdir = "/tmp"
     agent = PPO(None, policy, _Log(), storage, device, 1, seed=rank, precision=args.precision, **hp)
+    if args.no_merge:
+        agent.merge_accumulation = False
     if args.debug_flags:
         agent.engine.debug_flags(args.debug_flags)
     eng = agent.engine
