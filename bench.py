@@ -225,6 +225,8 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    from mi355.numa import pin_to_gpu_node
+    pin_to_gpu_node(local)                                  # host threads + pinned buffers on the GPU's NUMA node (MI355_NUMA_PIN=0: off)
     if world > 1:
         import torch.distributed as dist
         if args.rehearse_on_one_gpu:

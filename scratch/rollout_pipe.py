@@ -7,6 +7,9 @@ for p in (ROOT, os.path.join(ROOT, "train-procgen-pytorch_amd")):
     sys.path.insert(0, p)
 import numpy as np, torch
 from mi355.engine import Engine
+from mi355.numa import pin_to_gpu_node
+_pinned = pin_to_gpu_node(0)
+print('numa pin:', None if _pinned is None else len(_pinned), 'cpus')
 from mi355 import layout
 from common.model import ImpalaModel
 from common.policy import CategoricalPolicy

@@ -84,6 +84,21 @@ def test_layout_roundtrip_and_order():
     assert sum(int(np.prod(s)) for s in layout.mlp_param_shapes(2, 9, 4, 256, 64).values()) == 150787
 
 
+def test_numa_helper_parses_cpu_lists_and_is_a_no_op_without_a_gpu(monkeypatch):
+    """mi355.numa: sysfs cpu lists -> CPU sets; no GPU / unreadable topology / MI355_NUMA_PIN=0 / too few local CPUs leave the
+    affinity alone and return None."""
+    from mi355 import numa
+    assert numa._parse_cpulist("64-67,192-193\n") == {64, 65, 66, 67, 192, 193}
+    assert numa._parse_cpulist("5") == {5} and numa._parse_cpulist("\n") == set()
+    before = os.sched_getaffinity(0)
+    assert numa.pin_to_gpu_node(0) is None or numa.pin_to_gpu_node(0) <= before          # (a GPU box pins; this container has no GPU)
+    monkeypatch.setattr(numa, "gpu_numa_cpus", lambda i=0: {next(iter(before))})
+    assert numa.pin_to_gpu_node(0, min_cpus=2) is None and os.sched_getaffinity(0) == before      # one local CPU < min_cpus
+    monkeypatch.setenv("MI355_NUMA_PIN", "0")
+    monkeypatch.setattr(numa, "gpu_numa_cpus", lambda i=0: set(before))
+    assert numa.pin_to_gpu_node(0, min_cpus=1) is None and os.sched_getaffinity(0) == before
+
+
 def test_single_threaded_permutation_draw_is_torch_randperm():
     """The permutation is drawn with one intra-op thread (3 ms of idle GPU per optimize() otherwise): same numbers as torch.randperm at
     the production size, the generator advanced identically, the caller's thread count put back."""

@@ -221,6 +221,8 @@ def train_ppo(args):
         torch.distributed.broadcast(seed_t, 0)              # same initial weights and minibatch permutations on every rank
         args.seed = int(seed_t.item())
     set_global_seeds(args.seed)
+    from mi355.numa import pin_to_gpu_node
+    pin_to_gpu_node(int(getattr(args, "gpu_device", 0) or 0))      # (new) host threads + pinned buffers on the GPU's NUMA node
     device = torch.device("cuda", args.gpu_device)
     n_envs, n_steps = hp.get("n_envs", 256), hp.get("n_steps", 256)
     # the synthetic env's action count follows Procgen's: 15 combos, 9 after ActionWrapper merges duplicates (default, helper_local.py:653)
