@@ -26,6 +26,9 @@ __device__ __forceinline__ uint2 rb_pack(const float (&v)[4]) {
     return (uint2){mi_pk_bf16(v[0], v[1]), mi_pk_bf16(v[2], v[3])};
 }
 
+#ifndef RB_ROWPAD8
+#define RB_ROWPAD8 1
+#endif
 #ifndef RB_SWZ16
 #define RB_SWZ16 1       // 16-channel LDS images: chunk swap keyed on bit 2 of the column (0 = plain layout, for A/B timing)
 #endif
@@ -43,7 +46,11 @@ struct RbCfg {
     static constexpr int R1 = WHOLE ? HW : TH + 2;           // rows the first conv is evaluated on (per image)
     static constexpr int XR = R1 + 2;                        // staged input rows
     static constexpr int YR = TH + 2;                        // rows of the intermediate image (conv2's haloed input)
-    static constexpr int X_ELEMS = ((NIMG * XR * P * S + 7) / 8) * 8, Y_ELEMS = ((NIMG * YR * P * S + 7) / 8) * 8;
+    // row pitch of the haloed LDS images.  8x8 images: a 16-pixel MFMA tile is TWO rows of 8, and at 10 x 96 bytes per row the pixels (y, x)
+    // and (y + 1, x) sit 48 banks apart -- on the same bank pairs as their row-mates 8 and 2 columns on: every 8-byte epilogue / skip access
+    // 2-way (39 % of the pair kernel's LDS cycles).  16 bytes of padding per row move row y + 1 onto the other half of every 8-bank group.
+    static constexpr int RP = P * S + ((HW == 8 && RB_ROWPAD8) ? 8 : 0);
+    static constexpr int X_ELEMS = ((NIMG * XR * RP + 7) / 8) * 8, Y_ELEMS = ((NIMG * YR * RP + 7) / 8) * 8;
     static constexpr int NK = (C == 32) ? 9 : 5, WS = NK * 32 + 16, W_ELEMS = C * WS;
     static constexpr int NB = C / 16, C8 = C / 8;
     static constexpr int NMT1 = NIMG * R1 * HW / 16, NMT2 = NIMG * TH * HW / 16;     // M tiles (16 pixels) of the two convs
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
         int tap, chunk;
         if (C::C == 32) { tap = m; chunk = kq; } else { tap = 2 * m + (kq >> 1); chunk = kq & 1; if (tap > 8) tap = 8; }
         if (SWZ) chunk ^= ((i + tap % 3) >> 2) & 1;        // column of this lane's pixel under the tap (tiles start at columns 0 / 16)
-        koff[m] = ((tap / 3) * C::P + (tap % 3)) * C::S + chunk * 8;
+        koff[m] = (tap / 3) * C::RP + (tap % 3) * C::S + chunk * 8;
     }
     const int nwork = (a.n + C::NIMG - 1) / C::NIMG;
     uint4 regs[C::NLD];
@@ -367,14 +374,14 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
     // tile geometry: whole images, so both convs of both stages use the same pixel tiles (tile k of this wave = wave + NW*k) and the
     // haloed images s_x / s_y have the same shape: one LDS base + one global offset per tile serve everything
     static_assert(C::NMT1 == C::NMT2 && C::XR == C::YR, "whole-image geometry");
-    constexpr int CENTER = (C::P + 1) * C::S;            // from a tile pixel's window origin to the pixel itself
+    constexpr int CENTER = C::RP + C::S;                 // from a tile pixel's window origin to the pixel itself
     int abase[C::MT1], poff[C::MT1];                     // window origin in the haloed image; element offset of the pixel's channel quad in the item
     bool live[C::MT1];
 #pragma unroll
     for (int mt = 0; mt < C::MT1; ++mt) {
         int t = wave + C::NW * mt; live[mt] = t < C::NMT1; t = live[mt] ? t : C::NMT1 - 1;
         const int pl = t * 16 + i, px = pl % C::HW, ry = (pl / C::HW) % C::HW, img = pl / (C::HW * C::HW);
-        abase[mt] = ((img * C::XR + ry) * C::P + px) * C::S;
+        abase[mt] = (img * C::XR + ry) * C::RP + px * C::S;
         poff[mt] = pl * C::C + kq * 4;
     }
     if ((int)blockIdx.x < nwork) load(blockIdx.x * C::NIMG);
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
             if (e < C::NSRC) {
                 const int c8 = e % C::C8, px = (e / C::C8) % C::HW, rr = e / (C::C8 * C::HW);
                 const uint4 v = regs[k];
-                *(uint4*)(s_x + (rr * C::P + px + 1) * C::S + (SWZ ? (c8 ^ (((px + 1) >> 2) & 1)) : c8) * 8) = v;      // RAW: conv1 applies the ReLU on its operand reads, the skip reads it back
+                *(uint4*)(s_x + rr * C::RP + (px + 1) * C::S + (SWZ ? (c8 ^ (((px + 1) >> 2) & 1)) : c8) * 8) = v;      // RAW: conv1 applies the ReLU on its operand reads, the skip reads it back
             }
         }
         __syncthreads();
