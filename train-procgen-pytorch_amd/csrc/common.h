@@ -254,6 +254,9 @@ void launch_reduce_all_slabs(const float* ws, float* grads, const SlabDesc* d_de
 struct BankDesc { long long w_off, out_off; int rows, cin_pass, co_f, ci_f, transw, ws, nk; };
 int  bank_ws(int cin_pass);                 // elements per bank row
 void launch_pack_banks(const float* params, unsigned short* banks, const BankDesc* d_desc, int n_desc, hipStream_t st);
+// a launcher asked for a shape it has no kernel for: recorded here (thread-local), reported by the engine's next NETCHK as error -4
+void mi_launch_fail(const char* msg);
+const char* mi_launch_failed_take();      // the message (and clears it), or null
 void launch_heads_fwd(const float* feat, const float* Wh, const float* bh, float* hout, int n, int O /* <= 16 outputs, H == 256 */, hipStream_t st);
 void launch_pull_bytes(const void* host_src /* pinned, device-visible */, void* dst, size_t bytes /* multiple of 16 */, hipStream_t st);
 void launch_pull_i32(const int32_t* host_src /* pinned, device-visible */, int32_t* dst, int n, hipStream_t st);

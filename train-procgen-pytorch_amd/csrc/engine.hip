@@ -46,7 +46,8 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (r_ != ncclSuccess) return fail(-5, std::string(#x) + ": " + ncclGetErrorString(r_) + " @" + std::to_string(__LINE__)); \
     } while (0)
 #define ARG(c, msg) do { if (!(c)) return fail(-1, std::string("invalid argument: ") + msg); } while (0)
-#define NETCHK(c) do { if (!(c)->net_err.empty()) { std::string m_ = (c)->net_err; (c)->net_err.clear(); return fail(-4, m_); } } while (0)
+#define NETCHK(c) do { if (const char* lf_ = mi_launch_failed_take()) return fail(-4, lf_);                                   \
+                       if (!(c)->net_err.empty()) { std::string m_ = (c)->net_err; (c)->net_err.clear(); return fail(-4, m_); } } while (0)
 
 struct mi_ctx;
 static int join_groups(mi_ctx* c);
@@ -1123,6 +1124,7 @@ static int group_issue(mi_ctx* c, int g, const GroupJob& j) {
                         j.have_rd ? h_rd : nullptr, j.have_rd ? c->rew + o - E : nullptr, j.have_rd ? c->done + o - E : nullptr, st,
                         c->d_done_ctr + 1 + g, c->h_flag + 1 + g, j.ticket);
     HIPC(hipGetLastError());
+    if (const char* lf = mi_launch_failed_take()) return fail(-4, lf);      // (this worker thread's launchers)
     return 0;
 }
 static void group_worker_main(mi_ctx* c, int g) {

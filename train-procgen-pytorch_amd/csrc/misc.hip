@@ -5,6 +5,10 @@
 #include <math.h>
 #include <stdlib.h>
 
+static thread_local const char* tl_launch_err = nullptr;
+void mi_launch_fail(const char* msg) { if (!tl_launch_err) tl_launch_err = msg; }
+const char* mi_launch_failed_take() { const char* m = tl_launch_err; tl_launch_err = nullptr; return m; }
+
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 template <typename T>
@@ -319,14 +323,14 @@ void launch_maxpool_fwd_bf16(const void* in, void* out, uint8_t* arg, int n, int
     if (hw == 64 && c == 16) pool_fwd_bf_t<64, 16>(in, out, arg, n, st);
     else if (hw == 32 && c == 32) pool_fwd_bf_t<32, 32>(in, out, arg, n, st);
     else if (hw == 16 && c == 32) pool_fwd_bf_t<16, 32>(in, out, arg, n, st);
-    else abort();
+    else mi_launch_fail("max pool (bf16): unsupported image size / channel count");
 }
 void launch_maxpool_bwd_bf16(const void* dout, const uint8_t* arg, void* din, int n, int hw, int c, hipStream_t st) {
     if (n <= 0) return;
     if (hw == 64 && c == 16) pool_bwd_bf_t<64, 16>(dout, arg, din, n, st);
     else if (hw == 32 && c == 32) pool_bwd_bf_t<32, 32>(dout, arg, din, n, st);
     else if (hw == 16 && c == 32) pool_bwd_bf_t<16, 32>(dout, arg, din, n, st);
-    else abort();
+    else mi_launch_fail("max pool backward (bf16): unsupported image size / channel count");
 }
 
 template <int HW, int C>
@@ -344,14 +348,14 @@ void launch_maxpool_fwd(const float* in, float* out, uint8_t* arg, int n, int hw
     if (hw == 64 && c == 16) pool_fwd_t<64, 16>(in, out, arg, n, st);
     else if (hw == 32 && c == 32) pool_fwd_t<32, 32>(in, out, arg, n, st);
     else if (hw == 16 && c == 32) pool_fwd_t<16, 32>(in, out, arg, n, st);
-    else abort();
+    else mi_launch_fail("max pool: unsupported image size / channel count");
 }
 void launch_maxpool_bwd(const float* dout, const uint8_t* arg, float* din, int n, int hw, int c, hipStream_t st) {
     if (n <= 0) return;
     if (hw == 64 && c == 16) pool_bwd_t<64, 16>(dout, arg, din, n, st);
     else if (hw == 32 && c == 32) pool_bwd_t<32, 32>(dout, arg, din, n, st);
     else if (hw == 16 && c == 32) pool_bwd_t<16, 32>(dout, arg, din, n, st);
-    else abort();
+    else mi_launch_fail("max pool backward: unsupported image size / channel count");
 }
 
 // ------------------------------------------------------------------------------------------ slab / column reductions
@@ -901,7 +905,7 @@ __global__ __launch_bounds__(256) void fs_parts_seg_kernel(const float* part, in
 int fs_groups_per_segment(int n_seg) { int g = FS_TOTAL_GROUPS / (n_seg < 1 ? 1 : n_seg); int p = 32; while (p * 2 <= g) p *= 2; return p; }
 void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int d, float* colmax_scratch, double* fs_parts, hipStream_t stream) {
     if (st.n_seg <= 0) return;
-    if (d % (8 * FS_PARTS)) abort();
+    if (d % (8 * FS_PARTS)) { mi_launch_fail("feature-sparsity metric: the feature count must be a multiple of 64"); return; }
     const int G = fs_groups_per_segment(st.n_seg);
     if (bf16) hipLaunchKernelGGL(colmax_partial_seg_kernel<true>, dim3(G, st.n_seg), dim3(256), 0, stream, flat_pre, st, d, G, colmax_scratch);
     else hipLaunchKernelGGL(colmax_partial_seg_kernel<false>, dim3(G, st.n_seg), dim3(256), 0, stream, flat_pre, st, d, G, colmax_scratch);
@@ -910,7 +914,7 @@ void launch_fs_metric_seg(const void* flat_pre, int bf16, const SegTab& st, int 
 int fs_metric_groups() { return FS_GROUPS; }                    // row groups launch_fs_metric leaves in its scratch
 void launch_fs_metric(const void* flat_pre, int bf16, int n, int d, float* colmax_scratch, float* fs_out, hipStream_t st) {
     if (n <= 0) return;
-    if (d % 8) abort();                                       // the flattened IMPALA feature map (2048)
+    if (d % 8) { mi_launch_fail("feature-sparsity metric: the feature count must be a multiple of 8"); return; }      // the flattened IMPALA feature map (2048)
     hipLaunchKernelGGL(colmax_partial_kernel, dim3(FS_GROUPS), dim3(256), 0, st, flat_pre, bf16, n, d, colmax_scratch);
     hipLaunchKernelGGL(fs_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)colmax_scratch, FS_GROUPS, d, fs_out);
 }
