@@ -212,6 +212,10 @@ def main():
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic: mi_debug_flags bits (1: unfused rollout tail, 4: frames always uploaded by DMA copy, never pulled by a kernel)")
     ap.add_argument("--no-h2d", action="store_true", help="diagnostic: policy steps read frames already resident in HBM (no per-step upload); "
                     "the default uploads every step's E frames from pinned host memory inside the timed region, as the real loop must")
+    ap.add_argument("--engine-only", action="store_true", help="diagnostic: the rollout phase drives mi_rollout_submit / mi_rollout_wait directly with frames "
+                    "that already lie in pinned buffers (rounds 1-2's loop) instead of the product's collector PPO._collect on an EnvGroups env")
+    ap.add_argument("--n-actions", type=int, default=9, help="action count A: 9 = the reference's default for Procgen (ActionWrapper merges the 15 key "
+                    "combinations by name, helper_local.py:653), 15 = --no-reduce_duplicate_actions")
     ap.add_argument("--rollout-groups", type=int, default=0, help="env groups of the pipelined rollout (0 = auto: 4 when n_envs >= 128 divides, else 2; "
                     "1 = the reference's serial step: upload, forward, read-back one after the other)")
     args = ap.parse_args()
@@ -240,7 +244,7 @@ def main():
     from common.storage import Storage
 
     hp = yaml.safe_load(open(os.path.join(PKG, "hyperparams", "procgen", "config.yml")))[args.param_name]
-    T, E, A = hp["n_steps"], hp["n_envs"], 15
+    T, E, A = hp["n_steps"], hp["n_envs"], args.n_actions
     if args.rank_share > 1:
         hp["mini_batch_size"] //= args.rank_share
     torch.manual_seed(6033)
@@ -259,6 +263,8 @@ def main():
         agent.engine.debug_flags(args.debug_flags)
     eng = agent.engine
 
+    if args.no_h2d:
+        args.engine_only = True
     rng = np.random.default_rng(rank)
     rew = eng.pinned((T, E), np.float32)
     done = eng.pinned((T, E), np.float32)
@@ -275,7 +281,15 @@ def main():
         raise SystemExit(f"--rollout-groups {G} does not divide n_envs={E}")
     ng = E // G
     eng.rollout_groups(G)
-    if not args.no_h2d:
+    env = None
+    if not args.engine_only:
+        # the PRODUCT's rollout loop: PPO._collect on G synthetic sub-envs behind one VecEnv (common/env/vec_envs.py EnvGroups), each handing
+        # out fresh uint8 NHWC frames in ordinary host memory every step, rewards / dones / infos as an env would (agents/ppo.py:225-236:
+        # predict, env.step, Storage.store -- staging or in-place page-locking of the frames, note_stored and the info objects included)
+        from common.env.vec_envs import EnvGroups, SyntheticTape
+        env = EnvGroups([SyntheticTape(ng, A, seed=1000 * rank + g, length=T) for g in range(G)]) if G > 1 else SyntheticTape(E, A, seed=1000 * rank, length=T)
+        roll = {"obs": env.reset(), "hidden": np.zeros((E, storage.hidden_state_size), np.float32), "done": np.zeros(E, np.float32)}
+    if args.engine_only and not args.no_h2d:
         # what Procgen's rgb buffer would hand over: per env group a small ring of pinned (E/G,64,64,3) uint8 buffers
         host_frames = [[eng.pinned((ng, 64, 64, 3), np.uint8) for _ in range(4)] for _ in range(G)]
         for hg in host_frames:
@@ -301,18 +315,21 @@ def main():
 
     def iteration(it):
         t_r = time.perf_counter()
-        # T policy steps + the bootstrap-value step.  Per env group g the real loop's dependency chain is kept: the frames of step t
+        if env is not None:
+            agent._iter = it + 1
+            roll["obs"], roll["hidden"], roll["done"] = agent._collect(env, eng, storage, roll["obs"], roll["hidden"], roll["done"])
+        # (--engine-only) T policy steps + the bootstrap-value step.  Per env group g the real loop's dependency chain is kept: the frames of step t
         # go up only AFTER the group's actions of step t-1 have reached the host (rollout_wait; env.step(act) would run right there),
         # and with them the reward / done that env.step returned.  Groups are independent chains: while the host waits for group g,
         # the other groups' uploads and forward passes are in flight on their own streams.
-        for t in range(T + 1):
+        for t in range(T + 1 if env is None else 0):
             for g in range(G):
                 if t:
                     eng.rollout_wait(g)
                 sl = slice(g * ng, (g + 1) * ng)
                 eng.rollout_submit(t, g, None if host_frames is None else host_frames[g][t & 3],
                                    rew[t - 1, sl] if t else None, done[t - 1, sl] if t else None, seed=it)
-        for g in range(G):
+        for g in range(G if env is None else 0):
             eng.rollout_wait(g)
         phase["rollout_s"] += time.perf_counter() - t_r         # every group's last step has been read back: no extra sync
         t_e = time.perf_counter()
@@ -379,8 +396,10 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if args.precision == "bf16" else "f32"), "data": "synthetic" + (" -- REHEARSAL: every rank on GPU 0, gloo; not a result" if args.rehearse_on_one_gpu else ""),
                "config": {"workload": f"PPO iteration, {args.param_name}: IMPALA-CNN, T={T}, E={E} envs per GPU, "
                                       f"{hp['epoch']} epochs x {agent.n_minibatch} minibatches of {agent.mini_batch_size} (global), "
-                                      f"A={A} (--no-reduce_duplicate_actions; the reference default merges them to 9), "
-                                      + (f"every policy step uploads its E frames from pinned host memory (pipelined over {G} env groups)" if host_frames is not None
+                                      f"A={A}" + (" (the reference's default action set)" if A == 9 else " (--no-reduce_duplicate_actions)") + ", "
+                                      + (f"rollout = the product's PPO._collect on an EnvGroups of {G} synthetic sub-envs (fresh uint8 frames in ordinary host "
+                                         "memory every step, uploaded inside the timed region; Storage bookkeeping and info objects included)" if env is not None
+                                         else f"DIAGNOSTIC --engine-only: mi_rollout_submit / wait driven by bench.py, frames in pinned buffers ({G} env groups)" if host_frames is not None
                                          else "DIAGNOSTIC --no-h2d: frames resident in HBM, no per-step upload"),
                           "parallelism": f"dp{world} over n_envs"},
                "roofline": roof,

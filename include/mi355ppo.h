@@ -55,6 +55,12 @@ int mi_sync(mi_ctx* ctx);
  * buffer is a true asynchronous DMA (the reference copies pageable numpy arrays, agents/ppo.py:74-76) */
 void* mi_host_alloc(size_t bytes);
 void  mi_host_free(void* p);
+/* page-lock caller-owned memory in place -- the buffer an env hands its frames out in (Procgen's rgb buffer keeps its address from
+ * step to step) -- so that mi_rollout_submit / mi_put_obs DMA straight out of it: no staging copy on the host (the reference copies
+ * every observation twice on the host before its H2D, common/storage.py:39-44 and agents/ppo.py:74).  Negative where the runtime
+ * refuses the range; the caller then stages through mi_host_alloc memory as before. */
+int   mi_host_register(void* p, size_t bytes);
+int   mi_host_unregister(void* p);
 
 /* ---- parameters / optimiser state: flat fp32 vectors in the REFERENCE's policy.parameters() order and
  *      tensor layouts (policy.state_dict(), train.py:257-263 / agents/ppo.py:271-276).  The library
@@ -229,6 +235,10 @@ int mi_selftest_mfma(mi_ctx* ctx, float* max_err);
  * 1 res1.conv1 out, 2 res1 out, 3 res2.conv1 out, 4 block out, 5 max-pool arg-max (window position ky*3+kx); which = 100: features.
  * Lets a parity test run the oracle's backward pass on the ENGINE's forward tensors (teacher forcing, tests/test_gpu_bf16.py). */
 int mi_debug_read(mi_ctx* ctx, int32_t which, int32_t n, float* out);
+/* The production sampler's generator (dist.sample() of agents/ppo.py:77 is torch's; here Philox4x32-10 keyed by (seed, t*E + e)):
+ * n x {c0,c1,c2,c3,k0,k1} in; out4 = n x 4 output words of the ten-round bijection (checked against the Random123 known-answer
+ * vectors), u_out = n uniforms exactly as the sample kernels draw them for seed = k0 | k1 << 32, counter = c0 | c1 << 32. */
+int mi_debug_philox(mi_ctx* ctx, const uint32_t* ctr_key6, int32_t n, uint32_t* out4, float* u_out);
 /* bit 0 set: rollout-sized bf16 inference passes use the separate block-2 / block-3 kernels instead of the fused launch
  * (rollout_bf16.hip) -- the A side of the bit-equality test of the two paths;
  * bit 2 set: a group's frames always go up by DMA copy, never pulled by a kernel (A/B timing) */

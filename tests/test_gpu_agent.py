@@ -378,6 +378,7 @@ sys.path[:0] = [sys.argv[5], sys.argv[6]]
 precision = sys.argv[7] if len(sys.argv) > 7 else "fp32"
 xcoef = float(sys.argv[8]) if len(sys.argv) > 8 else 0.02
 fscoef = float(sys.argv[9]) if len(sys.argv) > 9 else 0.0
+rec = len(sys.argv) > 10 and sys.argv[10] == "rec"
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -389,7 +390,7 @@ from mi355 import engine as M
 T, EG, A = 4, 8, 15
 E = EG // world
 torch.manual_seed(6033)
-policy = CategoricalPolicy(ImpalaModel(3), False, A)
+policy = CategoricalPolicy(ImpalaModel(3), rec, A)
 storage = Storage((3, 64, 64), 256, T, E, torch.device("cuda", 0))
 class L: episode_reward_buffer = [0.0]; logdir = "/tmp"
 agent = PPO(None, policy, L(), storage, torch.device("cuda", 0), 1, n_steps=T, n_envs=E, epoch=1, n_minibatch=1,
@@ -405,20 +406,33 @@ for t in range(T + 1):
     eng.put_obs(t, frames[t, sl]); eng.sync()
 eng.write_field(M.F_ACT, act[:, sl].astype(np.float32)); eng.write_field(M.F_LOGP, logp[:, sl]); eng.write_field(M.F_VALUE, val[:, sl])
 eng.write_field(M.F_REW, rew[:, sl]); eng.write_field(M.F_DONE, done[:, sl])
+hid = np.zeros((E, 256), np.float32)
+if rec:
+    # hard-rec shape (config.yml:473-491; SURVEY 8(a) A9): the GRU runs in the ROLLOUT only -- each rank steps its own envs through
+    # mi_rec_state + mi_rollout_step (caller uniforms, so that one process and two ranks draw the same actions), which overwrites the
+    # ring's act / logp / value with what the recurrent policy produced; the update below then bypasses the GRU as the reference does
+    uu = rng.random((T + 1, EG)).astype(np.float32)
+    h0 = (0.1 * rng.standard_normal((EG, 256))).astype(np.float32)
+    eng.rec_state(h0[sl], None)
+    for t in range(T + 1):
+        eng.rollout_step(t, rew[t - 1, sl] if t else None, done[t - 1, sl] if t else None, seed=0, u=uu[t, sl])
+    hid = eng.get_hidden()
 storage.compute_estimates(0.999, 0.95, True, True, agent.coll)
 adv = eng.read_field(M.F_ADV)
 torch.manual_seed(5)
 summary = agent.optimize()
 if rank == 0:
-    np.savez(out, params=eng.get_params(), adv=adv, total=summary["Loss/total"], xent=summary["Loss/x_entropy"], fs=summary["Loss/feature_sparsity"])
+    np.savez(out, params=eng.get_params(), adv=adv, total=summary["Loss/total"], xent=summary["Loss/x_entropy"], fs=summary["Loss/feature_sparsity"],
+             logp=eng.read_field(M.F_LOGP), value=eng.read_field(M.F_VALUE), act=eng.read_field(M.F_ACT), hid=hid)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("precision,xcoef,fscoef", [("fp32", 0.02, 0.0), ("bf16", 0.02, 0.0), ("fp32", 0.0, 0.0), ("bf16", 0.0, 0.0),
-                                                    ("fp32", 0.0, 0.05), ("bf16", 0.02, 0.05)])
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path, precision, xcoef, fscoef):
+@pytest.mark.parametrize("precision,xcoef,fscoef,rec", [("fp32", 0.02, 0.0, ""), ("bf16", 0.02, 0.0, ""), ("fp32", 0.0, 0.0, ""), ("bf16", 0.0, 0.0, ""),
+                                                        ("fp32", 0.0, 0.05, ""), ("bf16", 0.02, 0.05, ""),
+                                                        ("fp32", 0.0, 0.0, "rec"), ("bf16", 0.0, 0.0, "rec")])
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path, precision, xcoef, fscoef, rec):
     """The real multi-rank engine path (mi_set_multirank, loss-stats + gradient all-reduce on aliased device
     buffers, merged advantage statistics) with 2 processes sharing the GPU over `gloo`, against the 1-process run
     on the same global rollout and the same permutation stream: one optimizer step fed by two accumulated
@@ -430,17 +444,27 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, precision, xcoef, f
     takes mode 2 (statistics ring reduced once per optimize(), mi_loss_log_finalize).
     fscoef != 0: mode 1 plus the max-all-reduce of the per-column (value, global position) candidates -- the gradient of
     fs_coef * mean_j max_b tanh(|100 h_bj|) lands on the globally first row attaining each column maximum, whichever rank holds it, and
-    the logged metric is the global one."""
+    the logged metric is the global one.
+    rec = "rec" (BASELINE config 5's shape, `hard-rec`): a recurrent policy -- the GRU cell inside every rank's rollout steps (actions,
+    log-probs, values and the final hidden state of rank 0's envs equal the single process's), the recurrent minibatch stream
+    (torch.randperm(E_global) env groups, all T steps of an env together, common/storage.py:93-110) sharded by env owner -- a rank's share
+    of an env group can be EMPTY -- and the update that bypasses the GRU (agents/ppo.py:123-128)."""
     script = tmp_path / "two_rank.py"
     script.write_text(_TWO_RANK)
     port = str(29600 + os.getpid() % 1000)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = str(tmp_path / "one.npz"); two = str(tmp_path / "two.npz")
-    subprocess.run([sys.executable, str(script), "0", "1", port, one, ROOT, PKG, precision, str(xcoef), str(fscoef)], check=True, env=env, timeout=300)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, two, ROOT, PKG, precision, str(xcoef), str(fscoef)], env=env) for r in range(2)]
+    subprocess.run([sys.executable, str(script), "0", "1", port, one, ROOT, PKG, precision, str(xcoef), str(fscoef), rec], check=True, env=env, timeout=300)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, two, ROOT, PKG, precision, str(xcoef), str(fscoef), rec], env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     a, b = np.load(one), np.load(two)
+    if rec:             # the recurrent rollout: same actions; log-probs / values / hidden state up to the GRU GEMMs' summation order (M = 8 vs 4 rows)
+        assert np.array_equal(b["act"], a["act"][:, :4]) and len(np.unique(a["act"])) > 2
+        np.testing.assert_allclose(b["logp"], a["logp"][:, :4], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(b["value"], a["value"][:, :4], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(b["hid"], a["hid"][:4], rtol=0, atol=2e-6)
+        assert np.abs(a["hid"]).max() > 1e-3
     np.testing.assert_allclose(b["adv"], a["adv"][:, :4], rtol=0, atol=2e-6)        # rank 0 owns envs 0..3
     assert abs(float(a["total"]) - float(b["total"])) < 1e-5 and abs(float(a["xent"]) - float(b["xent"])) < 1e-6
     np.testing.assert_allclose(b["params"], a["params"], rtol=0, atol=2e-6)

@@ -393,16 +393,91 @@ def test_policy_step_sampling():
     eng.close()
 
 
-@pytest.mark.parametrize("arch,precision,groups,dma", [("impala", "bf16", 2, False), ("impala", "bf16", 2, True), ("impala", "fp32", 4, False),
-                                                        ("mlp", "fp32", 2, False)])
-def test_pipelined_rollout_groups_equal_serial_steps(arch, precision, groups, dma):
+def test_philox_known_answers_and_the_samplers_uniforms():
+    """The generator every real rollout samples with (csrc/misc.hip philox4x32_10 / philox_uniform) against (a) the Random123
+    known-answer vectors for philox4x32 with 10 rounds (counter 0 / key 0, all ones, the pi digits), (b) the numpy restatement
+    oracle/philox.py -- itself pinned to the same vectors on the CPU -- on 100 000 random (counter, key) pairs, bit for bit, and (c) the
+    float conversion: the uniform the sample kernels draw for (seed, counter) is the top 24 bits of word 0 times 2^-24."""
+    from oracle import philox as P
+    eng = make_engine("mlp", 2, 4, 2, 4)
+    kat = np.array([list(c) + list(k) for c, k, _ in P.KAT], dtype=np.uint32)
+    out, _ = eng.debug_philox(kat)
+    for (c, k, want), got in zip(P.KAT, out):
+        assert tuple(int(x) for x in got) == want, (c, k, [hex(int(x)) for x in got])
+    rng = np.random.default_rng(9)
+    ck = rng.integers(0, 2 ** 32, size=(100000, 6), dtype=np.uint64).astype(np.uint32)
+    ck[:1000, 2:4] = 0                                              # the sampler's own form: a 64-bit counter in words 0-1
+    ck[:100, 1] = 0; ck[:100, 0] = np.arange(100)                   # ... and small counters t*E + e
+    out, u = eng.debug_philox(ck)
+    assert np.array_equal(out, P.philox4x32_10(ck[:, :4], ck[:, 4:]))
+    for i in (0, 50, 999):
+        seed = int(ck[i, 4]) | (int(ck[i, 5]) << 32)
+        ctr = int(ck[i, 0]) | (int(ck[i, 1]) << 32)
+        assert u[i] == P.uniform(seed, [ctr])[0]
+    first = P.philox4x32_10(np.concatenate([ck[:, :2], np.zeros_like(ck[:, :2])], 1), ck[:, 4:])[:, 0]
+    assert np.array_equal(u, (first >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24))
+    assert u.min() >= 0.0 and u.max() < 1.0
+    eng.close()
+
+
+def test_sampled_action_frequencies_follow_the_policy_distribution():
+    """dist.sample() (agents/ppo.py:77) through the PRODUCTION path -- Philox uniforms, inverse CDF inside heads_sample_kernel --
+    on 2 M draws: for each of E = 256 observations the policy's action distribution is fixed, 8192 rollout steps with different
+    (seed, t) each draw one action per env.  Pearson chi^2 of the counts against n * exp(logp) (logp from mi_forward, the
+    distribution object the reference samples from) summed over the envs: E * (A - 1) degrees of freedom, accepted within 5 sigma
+    of its mean (a generator with a wrong round count would still be uniform -- the known-answer test above catches that; this one
+    catches a biased float conversion, an off-by-one CDF edge or correlated counters: all shift the statistic by hundreds of sigma).
+    Also checks the returned log-prob is the log-probability of the returned action."""
+    from mi355 import layout
+    T, E, A, R = 7, 256, 15, 8192
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(E, 64, 64, 3), dtype=np.uint8)
+    params = dict(golden_params("impala"))
+    params["fc_policy.weight"] = params["fc_policy.weight"] * 150.0        # spread but no cell below ~0.5 % probability
+    eng = make_engine("impala", T, E, A, E)
+    eng.set_params(layout.flatten(shapes_for("impala", A), params))
+    for t in range(T + 1):
+        eng.put_obs(t, frames)
+    lp_all, _ = eng.forward(frames)
+    p = np.exp(lp_all.astype(np.float64))
+    assert abs(p.sum(1) - 1).max() < 1e-5
+    counts = np.zeros((E, A), np.int64)
+    rows = np.arange(E)
+    for r in range(R):
+        a, lp, _ = eng.rollout_step(r % T, seed=1000 + r // T)
+        np.add.at(counts, (rows, a), 1)
+        if r < 8:
+            np.testing.assert_allclose(lp, lp_all[rows, a], rtol=0, atol=2e-6)
+    eng.close()
+    exp = R * p
+    keep = exp >= 5.0
+    chi2 = float((((counts - exp) ** 2 / np.where(keep, exp, 1.0)) * keep).sum())
+    # cells below 5 expected counts are pooled per env into one cell
+    pooled_obs, pooled_exp = (counts * ~keep).sum(1), (exp * ~keep).sum(1)
+    has = pooled_exp > 0
+    chi2 += float((((pooled_obs - pooled_exp) ** 2) / np.where(has, pooled_exp, 1.0) * has).sum())
+    dof = int(keep.sum() + has.sum() - E)
+    z = (chi2 - dof) / np.sqrt(2.0 * dof)
+    print(f"chi2 {chi2:.1f} on {dof} dof: z = {z:+.2f}; smallest cell probability {p.min():.4f}")
+    assert abs(z) < 5.0, (chi2, dof, z)
+    # marginal check, independent of the per-env cells: the 2 M uniforms behind the draws are uniform -> the mean CDF position is 1/2
+    assert len(np.unique(counts.argmax(1))) > 1
+
+
+@pytest.mark.parametrize("arch,precision,groups,dma,E", [("impala", "bf16", 2, False, 32), ("impala", "bf16", 2, True, 32), ("impala", "fp32", 4, False, 32),
+                                                          ("mlp", "fp32", 2, False, 32),
+                                                          # the shapes that ship: C2 `easy` (E = 64 in 2 groups: 393 KB uploads, pulled by a kernel) and the
+                                                          # bench's hard-500 rollout (E = 256 in 4 groups: 786 KB uploads on the copy engine, link turn-taking on)
+                                                          ("impala", "bf16", 2, False, 64), ("impala", "fp32", 2, False, 64),
+                                                          ("impala", "bf16", 4, False, 256), ("impala", "fp32", 4, False, 256)])
+def test_pipelined_rollout_groups_equal_serial_steps(arch, precision, groups, dma, E):
     """mi_rollout_submit / mi_rollout_wait over G env groups (own streams, own rows of the activation buffers, frames uploaded by the
     submit) leave the ring and return the numbers of the serial mi_put_obs + mi_rollout_step loop: bit-equal actions / log-probs /
     values / rewards / dones / frames (same kernels on the same rows; Philox counters t*E + e in both).  Group uploads this small are
     pulled from the pinned buffer by a kernel; dma=True (mi_debug_flags bit 2) sends them through the copy engine like the large ones."""
     from mi355 import engine as M, layout
     from mi355.engine import Engine
-    T, E, A = 3, 32, (15 if arch == "impala" else 2)
+    T, A = (3 if E == 32 else 4), (15 if arch == "impala" else 2)
     rng = np.random.default_rng(17)
     params = dict(golden_params(arch))
     params["fc_policy.weight"] = params["fc_policy.weight"] * 200.0

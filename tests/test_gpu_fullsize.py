@@ -23,7 +23,7 @@ torch.set_num_threads(16)
 T, E, A, B = 32, 256, 15, 8192
 
 
-def _rollout(seed=0):
+def _rollout(seed=0, T=T, E=E):
     rng = np.random.default_rng(seed)
     frames = rng.integers(0, 256, size=(T + 1, E, 64, 64, 3), dtype=np.uint8)
     frames[3, 7, 10:40, 5:50] = 200                      # a flat patch: max-pool ties
@@ -37,6 +37,7 @@ def _engine(ro, precision, max_batch):
     from mi355.engine import Engine
     shapes = layout.impala_param_shapes(A)
     params = npz_params(load_npz("g3_impala_forward.npz"))
+    T, E = ro["rew"].shape
     eng = Engine("impala", T, E, A, max_batch, precision=precision)
     eng.set_params(layout.flatten(shapes, params))
     for t in range(T + 1):
@@ -114,3 +115,113 @@ def test_bf16_1024_minibatch_against_the_bf16_oracle():
     check_bf16_minibatch_against_oracle(eng, shapes, params, ro["frames"][:-1].reshape(-1, 64, 64, 3), idx,
                                         (ro["act"], ro["logp"], ro["val"][:-1], ret, adv), {})
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 2 (`easy`)
+# E = 64, T = 256 (a full 202 MB ring: slot indices to 16 383), ONE minibatch = 2048 samples -- the launch sizes of
+# `train.py --param_name easy` / `bench.py --param_name easy` (config.yml:21-39), which the 8192-sample tests above do not reach
+# (other persistent-grid sizes, other slab counts, fc kernels at n = 2048).
+TE, EE, BE = 256, 64, 2048
+
+
+def test_easy_fp32_one_2048_minibatch_against_the_oracle():
+    from mi355 import engine as M, layout
+    ro = _rollout(4, TE, EE)
+    eng, shapes, params = _engine(ro, "fp32", BE)
+    adv, ret = eng.read_field(M.F_ADV), eng.read_field(M.F_RET)
+    a_o, r_o = O.compute_estimates(torch.from_numpy(ro["rew"]), torch.from_numpy(ro["done"]), torch.from_numpy(ro["val"]), 0.999, 0.95)
+    assert np.array_equal(ret, r_o.numpy()) and np.abs(adv - a_o.numpy()).max() < 2e-6       # the T = 256 scan, bit-exact returns
+    idx = np.random.default_rng(5).permutation(TE * EE)[:BE]                                  # one minibatch of the epoch's permutation
+    assert idx.max() > 16000 and idx.min() < 400                                              # ... reaching both ends of the ring
+    eng.minibatch(idx, BE, eng.hparams())
+    rec = eng.loss_log()[0]
+    mine = layout.unflatten(shapes, eng.get_grads())
+    eng.close()
+    ag = O.OraclePPO(params, "impala", TE, EE, epoch=1, n_minibatch=1, mini_batch_size=BE)
+    obs = O.frames_to_obs(ro["frames"][:-1].reshape(-1, 64, 64, 3)[idx])
+    f = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(-1)[idx])
+    L, g = ag.loss_and_grads(obs, f(ro["act"]), f(ro["logp"]), f(ro["val"][:-1]), f(ret), f(adv))
+    for j, k in enumerate(("pi_loss", "value_loss", "entropy", "x_ent", "total", "fs")):
+        assert abs(rec[j] - L[k]) < 1e-5 * max(1.0, abs(L[k])), (k, rec[j], L[k])
+    worst = max((_rel(mine[k], v.numpy()), k) for k, v in g.items())
+    print("easy: worst gradient tensor (relative L2)", worst)
+    assert worst[0] < 5e-3, worst
+
+
+def test_easy_bf16_one_2048_pass_equals_two_accumulated_1024_passes():
+    from mi355 import layout
+    ro = _rollout(5, TE, EE)
+    idx = np.random.default_rng(6).permutation(TE * EE)[:BE]
+    out = []
+    for parts in (1, 2):
+        eng, shapes, _ = _engine(ro, "bf16", BE)
+        for c in np.split(idx, parts):
+            eng.minibatch(c, BE, eng.hparams())
+        log = eng.loss_log()
+        out.append((layout.unflatten(shapes, eng.get_grads()), log[:, :5].sum(0), eng.optimizer_step(5e-4, 0.5, 1, want_norm=True), eng.get_params()))
+        eng.close()
+    (g1, l1, n1, p1), (g2, l2, n2, p2) = out
+    for j in range(3):
+        assert abs(l1[j] - l2[j]) < 2e-5 * max(1.0, abs(l1[j])), (j, l1[j], l2[j])
+    worst = max((_rel(g2[k], g1[k]), k) for k in g1)
+    print("easy: worst gradient tensor, 2 x 1024 vs 1 x 2048 (relative L2)", worst)
+    assert worst[0] < 1e-4, worst
+    assert abs(n1 - n2) < 1e-5 * n1 and np.abs(p1 - p2).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ the full hard-500 ring
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_minibatch_from_the_full_hard500_ring_equals_the_same_samples_in_a_compact_ring(precision):
+    """BASELINE config 3's ring -- T = 256, E = 256: 257 slots x 256 frames = 808 MB, flat indices t*E + e up to 65 535 -- was touched
+    by bench.py alone.  Size-independent property: a minibatch is a gather by index, so 8192 samples drawn from all over the full ring
+    must give the numbers of the same 8192 samples laid out back to back in a 32-step ring read with indices 0 .. 8191 -- same kernels,
+    same sample order, same grids, hence BIT-equal loss record, gradients and parameters after the optimizer step (the 32-step ring at
+    this batch is what the oracle tests above pin)."""
+    from mi355 import engine as M, layout
+    from mi355.engine import Engine
+    TF, EF = 256, 256
+    rng = np.random.default_rng(11)
+    shapes = layout.impala_param_shapes(A)
+    flat = layout.flatten(shapes, npz_params(load_npz("g3_impala_forward.npz")))
+    idx = rng.permutation(TF * EF)[:B]
+    assert idx.max() > 65000 and idx.min() < 100
+    sc = dict(act=rng.integers(0, A, (TF, EF)).astype(np.float32), logp=(np.log(1 / A) + 0.3 * rng.standard_normal((TF, EF))).astype(np.float32),
+              val=(0.5 * rng.standard_normal((TF + 1, EF))).astype(np.float32), ret=rng.standard_normal((TF, EF)).astype(np.float32),
+              adv=rng.standard_normal((TF, EF)).astype(np.float32))
+    full = Engine("impala", TF, EF, A, B, precision=precision)
+    full.set_params(flat)
+    compact = np.empty((B, 64, 64, 3), np.uint8)
+    order = np.argsort(idx // EF, kind="stable")
+    bounds = np.searchsorted((idx // EF)[order], np.arange(TF + 2))
+    for t in range(TF + 1):
+        fr = rng.integers(0, 256, size=(EF, 64, 64, 3), dtype=np.uint8)
+        full.put_obs(t, fr); full.sync()
+        js = order[bounds[t]:bounds[t + 1]]
+        compact[js] = fr[idx[js] % EF]
+    for f_, k in ((M.F_ACT, "act"), (M.F_LOGP, "logp"), (M.F_VALUE, "val"), (M.F_RET, "ret"), (M.F_ADV, "adv")):
+        full.write_field(f_, sc[k])
+    full.minibatch(idx, B, full.hparams())
+    rec_f, g_f = full.loss_log()[0], full.get_grads()
+    full.optimizer_step(5e-4, 0.5, 1)
+    p_f = full.get_params()
+    full.close()
+
+    TS = B // EF
+    small = Engine("impala", TS, EF, A, B, precision=precision)
+    small.set_params(flat)
+    for t in range(TS):
+        small.put_obs(t, compact[t * EF:(t + 1) * EF]); small.sync()
+    small.put_obs(TS, compact[:EF]); small.sync()
+    pick = lambda a: np.ascontiguousarray(a[:TF].reshape(-1)[idx].reshape(TS, EF))
+    small.write_field(M.F_ACT, pick(sc["act"])); small.write_field(M.F_LOGP, pick(sc["logp"]))
+    small.write_field(M.F_VALUE, np.concatenate([pick(sc["val"]), np.zeros((1, EF), np.float32)]))
+    small.write_field(M.F_RET, pick(sc["ret"])); small.write_field(M.F_ADV, pick(sc["adv"]))
+    small.minibatch(np.arange(B), B, small.hparams())
+    rec_s, g_s = small.loss_log()[0], small.get_grads()
+    small.optimizer_step(5e-4, 0.5, 1)
+    p_s = small.get_params()
+    small.close()
+    assert np.isfinite(rec_f[:5]).all() and np.abs(g_f).max() > 0
+    assert np.array_equal(rec_f, rec_s), (rec_f, rec_s)
+    assert np.array_equal(g_f, g_s), float(np.abs(g_f - g_s).max())
+    assert np.array_equal(p_f, p_s)

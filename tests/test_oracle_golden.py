@@ -270,3 +270,14 @@ def test_feature_sparsity_term_matches_reference():
                     r = z[k].astype(np.float64); m = gg[k[len(tag) + 3:]].numpy().astype(np.float64)
                     assert np.sqrt(((m - r) ** 2).sum()) < 1e-4 * np.sqrt((r ** 2).sum()) + 1e-9, (tag, k)
     assert float(z["fs/grad_total_norm"]) > 10 * float(z["fs0/grad_total_norm"])          # the term dominates this fixture's gradient
+
+
+def test_philox_restatement_against_the_random123_known_answers():
+    """oracle/philox.py (the checker of the engine's sampler) against the published philox4x32-10 vectors; uniforms are 24-bit."""
+    from oracle import philox as P
+    for c, k, want in P.KAT:
+        got = P.philox4x32_10([c], [k])[0]
+        assert tuple(int(x) for x in got) == want
+    u = P.uniform(12345678901234567, np.arange(200000, dtype=np.uint64) + (1 << 33))
+    assert u.dtype == np.float32 and u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 5e-3
+    assert np.array_equal(u * 16777216.0, np.floor(u * 16777216.0))

@@ -282,34 +282,55 @@ class PPO(BaseAgent):
     def _collect_pipelined(self, env, engine, storage, obs, hidden_state, done):
         """The same T steps + bootstrap step with the env groups of `env.env_groups` as independent chains (mi_rollout_submit /
         mi_rollout_wait): while the host waits for / steps group g, the other groups' frame uploads and forward passes run on
-        their own streams.  Device ring and returned arrays are those of `_collect` (same kernels, same sampling counters)."""
+        their own streams.  Device ring and returned arrays are those of `_collect` (same kernels, same sampling counters).
+
+        Host work per group step is kept to what the chain needs: a group's frames go up FROM THE ENV'S OWN BUFFER when that can be
+        page-locked in place (Engine.dma_ready: uint8 NHWC arrays an env hands out again and again -- Procgen's rgb buffer, a pool),
+        and only otherwise through a copy into a pinned staging buffer (786 KB per group step at E = 256: tens of microseconds of one
+        core inside a ~105 us dependency chain); results are written into this call's arrays through raw addresses; a step's infos
+        stay per-group objects (StepInfo.join), nothing is walked entry by entry."""
+        from common.env.vec_envs import StepInfo
         groups = env.env_groups
         G, E, T = len(groups), self.n_envs, self.n_steps
         ng = E // G
         key = id(engine)
+        arch = self.policy.arch
         if getattr(engine, "n_groups", 1) != G:
             engine.rollout_groups(G)
-        st = self._gstage.setdefault(key, [[engine.pinned((ng,) + self._obs_stage_shape(self.policy.arch, self.policy.embedder),
-                                                          self._obs_dtype(self.policy.arch)) for _ in range(2)] for _ in range(G)])
+        st = self._gstage.setdefault(key, [[engine.pinned((ng,) + self._obs_stage_shape(arch, self.policy.embedder),
+                                                          self._obs_dtype(arch)) for _ in range(2)] for _ in range(G)])
         obs_g = [obs[g * ng:(g + 1) * ng] for g in range(G)]
         rew = np.zeros(E, np.float32); dn = np.zeros(E, np.float32)
         act = np.zeros(E, np.int64); logp = np.zeros(E, np.float32); val = np.zeros(E, np.float32)
+        pa, pl, pv = (a.__array_interface__['data'][0] for a in (act, logp, val))
+        sls = [slice(g * ng, (g + 1) * ng) for g in range(G)]
         infos = [None] * G
         seed = self.seed * 1000003 + self._iter
+        want_dtype = self._obs_dtype(arch)
+        wait, submit, ready = engine.rollout_wait_into, engine.rollout_submit, engine.dma_ready
         for t in range(T + 1):
             for g in range(G):
-                sl = slice(g * ng, (g + 1) * ng)
+                sl = sls[g]
                 if t:
-                    act[sl], logp[sl], val[sl] = engine.rollout_wait(g)
-                    obs_g[g], r, d, infos[g] = groups[g].step(act[sl])
+                    wait(g, pa + 8 * sl.start, pl + 4 * sl.start, pv + 4 * sl.start)
+                    o, r, d, infos[g] = groups[g].step(act[sl])
+                    obs_g[g] = o
                     rew[sl] = r; dn[sl] = d
-                buf = st[g][t & 1]
-                buf[...] = as_device_obs(obs_g[g], self.policy.arch)
-                engine.rollout_submit(t, g, buf, rew[sl] if t else None, dn[sl] if t else None, seed=seed)
+                else:
+                    o = obs_g[g]
+                # upload in place when the env's array already is what the ring stores, else convert / copy into the pinned stage
+                if t and isinstance(o, np.ndarray) and o.dtype == want_dtype and o.flags.c_contiguous and (arch != "impala" or o.shape[-1] == 3) and ready(o):
+                    buf = o
+                else:
+                    buf = st[g][t & 1]
+                    buf[...] = as_device_obs(o, arch)
+                submit(t, g, buf, rew[sl] if t else None, dn[sl] if t else None, seed=seed)
             if t:
-                storage.note_stored(rew, dn, [i for x in infos for i in x], hidden_state)
+                if self.detect_nan and not (np.isfinite(val).all() and np.isfinite(logp).all()):
+                    raise RuntimeError(f"Found NaN / Inf in the policy outputs of rollout step {t - 1}")
+                storage.note_stored(rew, dn, StepInfo.join(infos), hidden_state)
         for g in range(G):
-            engine.rollout_wait(g)
+            wait(g, pa + 8 * sls[g].start, pl + 4 * sls[g].start, pv + 4 * sls[g].start)
         obs = np.concatenate(obs_g)
         storage._hidden[T] = hidden_state                    # store_last: value[T] and the frames are already in the device ring
         return obs, hidden_state, dn.copy()

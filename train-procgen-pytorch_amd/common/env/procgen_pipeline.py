@@ -151,8 +151,10 @@ class ProcgenFrameSource:
     def step_wait(self):
         obs, rews, news, infos = self.venv.step_wait()
         if self._rew is not None:
-            for i in range(len(infos)):
-                infos[i]['env_reward'] = rews[i]
+            # VecNormalize.step_wait writes infos[i]['env_reward'] = rews[i] into every env's dict (procgen_wrappers.py:336-337): here one
+            # column beside the env's own dicts (StepInfo: info[i]['env_reward'] reads the same value)
+            from common.env.vec_envs import StepInfo
+            infos = StepInfo(len(infos), {"env_reward": rews}, rows=infos)
             rews = self._rew(rews, news)
         return self._frames(obs), rews, news, infos
 

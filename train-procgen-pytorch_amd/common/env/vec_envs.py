@@ -16,6 +16,60 @@ class _Space:
         self.shape, self.n = shape, n
 
 
+class StepInfo:
+    """One vector-env step's `info`, kept column-wise.
+
+    The reference's protocol hands the agent a list of E dicts per step and walks them entry by entry afterwards
+    (`Storage.fetch_log_data`, common/storage.py:130-162: T*E dict look-ups per iteration; `VecNormalize.step_wait`,
+    procgen_wrappers.py:336-337: E dict writes per step).  A StepInfo answers to the same uses -- len(), info[i] -> dict,
+    iteration, `'key' in info[0]` -- but holds what the wrappers add (`env_reward`, ...) as ONE array per key and leaves the
+    env's own per-env dicts (`rows`, e.g. Procgen's prev_level_seed / level_complete) untouched; `column(key)` is what the logging
+    path reads.  `StepInfo.join(parts)` shows the infos of several env groups as one step's info without copying."""
+    __slots__ = ("n", "columns", "rows", "parts")
+
+    def __init__(self, n, columns=None, rows=None, parts=None):
+        self.n, self.columns, self.rows, self.parts = n, columns or {}, rows, parts
+
+    @staticmethod
+    def join(parts):
+        parts = [p if isinstance(p, StepInfo) else StepInfo(len(p), rows=p) for p in parts]
+        return parts[0] if len(parts) == 1 else StepInfo(sum(p.n for p in parts), parts=parts)
+
+    def __len__(self):
+        return self.n
+
+    def has(self, key):
+        if self.parts is not None:
+            return bool(self.parts) and self.parts[0].has(key)
+        return key in self.columns or bool(self.rows) and key in self.rows[0]
+
+    def column(self, key):
+        if self.parts is not None:
+            return np.concatenate([p.column(key) for p in self.parts])
+        if key in self.columns:
+            return np.asarray(self.columns[key])
+        return np.array([r[key] for r in self.rows])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self.n))]
+        if i < 0:
+            i += self.n
+        if self.parts is not None:
+            for p in self.parts:
+                if i < p.n:
+                    return p[i]
+                i -= p.n
+            raise IndexError(i)
+        d = dict(self.rows[i]) if self.rows else {}
+        for k, v in self.columns.items():
+            d[k] = v[i]
+        return d
+
+    def __iter__(self):
+        return (self[i] for i in range(self.n))
+
+
 class CartPoleVec:
     gravity, masscart, masspole, length, force_mag, tau = 9.8, 1.0, 0.1, 0.5, 10.0, 0.02
     x_threshold, theta_threshold = 2.4, 12 * 2 * np.pi / 360
@@ -68,6 +122,7 @@ class SyntheticFrames:
         self.action_space = _Space(n=n_actions)
         self._pool = [self.rng.integers(0, 256, size=(n_envs, 64, 64, 3), dtype=np.uint8) for _ in range(pool)]
         self._k = 0
+        self._level = np.arange(n_envs) % 500
 
     def _obs(self):
         self._k = (self._k + 1) % len(self._pool)
@@ -79,11 +134,28 @@ class SyntheticFrames:
     def step(self, act):
         rew = self.rng.standard_normal(self.n_envs).astype(np.float32)
         done = self.rng.random(self.n_envs) < 0.01
-        info = [{"env_reward": float(r), "prev_level_seed": e % 500} for e, r in enumerate(rew)]
-        return self._obs(), rew, done, info
+        return self._obs(), rew, done, StepInfo(self.n_envs, {"env_reward": rew, "prev_level_seed": self._level})
 
     def close(self):
         pass
+
+
+class SyntheticTape(SyntheticFrames):
+    """SyntheticFrames with every random draw made up front (a tape of `length` steps, replayed in a loop): step() is a few
+    microseconds of host work whatever n_envs is.  bench.py's stand-in for the Procgen engine -- the metric excludes env.step's own
+    cost, and a group's env.step sits INSIDE the rollout's dependency chain, so the stand-in must not be what the chain waits for.
+    Frames are handed out from a small pool of ordinary (pageable) numpy arrays, as an engine would from its own buffers."""
+
+    def __init__(self, n_envs, n_actions=15, seed=0, pool=4, length=256):
+        super().__init__(n_envs, n_actions, seed, pool)
+        self._rew = self.rng.standard_normal((length, n_envs)).astype(np.float32)
+        self._done = self.rng.random((length, n_envs)) < 0.01
+        self._info = [StepInfo(n_envs, {"env_reward": self._rew[i], "prev_level_seed": self._level}) for i in range(length)]
+        self._i = -1
+
+    def step(self, act):
+        self._i = i = (self._i + 1) % len(self._info)
+        return self._obs(), self._rew[i], self._done[i], self._info[i]
 
 
 class EnvGroups:
@@ -110,7 +182,7 @@ class EnvGroups:
             n = getattr(e, "n_envs", getattr(e, "num_envs", 0))
             outs.append(e.step(act[o:o + n])); o += n
         return (np.concatenate([x[0] for x in outs]), np.concatenate([x[1] for x in outs]), np.concatenate([x[2] for x in outs]),
-                [i for x in outs for i in x[3]])
+                StepInfo.join([x[3] for x in outs]))
 
     def reward_state(self):
         rs = getattr(self.env_groups[0], "reward_state", None)

@@ -202,22 +202,27 @@ class Storage:
             yield tuple(sample)
 
     def fetch_log_data(self):
-        """storage.py:130-162 on the host mirrors (no device read-back)."""
+        """storage.py:130-162 on the host mirrors (no device read-back).  Column-wise: a step's `info` is read as one array per key
+        (common/env/vec_envs.py StepInfo, or gathered once from a list of dicts) and only the envs whose episode ended are looked at
+        one by one -- the reference walks all T*E dicts three times."""
         T = self.num_steps
-        first = self.info_batch[0][0] if len(self.info_batch) and len(self.info_batch[0]) else {}
-        if 'env_reward' in first:
-            rew_batch = np.array([[i['env_reward'] for i in self.info_batch[s]] for s in range(T)])
-        else:
-            rew_batch = np.array(self._rew)
-        if 'env_done' in first:
-            done_batch = np.array([[i['env_done'] for i in self.info_batch[s]] for s in range(T)])
-        else:
-            done_batch = np.array(self._done)
-        if 'prev_level_seed' in first:
-            for s in range(T):
-                for e in np.nonzero(done_batch[s] > 0)[0]:
-                    info = self.info_batch[s][e]
-                    self.performance_track.setdefault(info["prev_level_seed"], deque(maxlen=10)).append(info["env_reward"])
+        infos = list(self.info_batch)
+
+        def has(info, key):
+            if hasattr(info, "has"):
+                return info.has(key)
+            return len(info) > 0 and key in info[0]
+
+        def col(info, key):
+            return info.column(key) if hasattr(info, "column") else np.array([i[key] for i in info])
+
+        first = infos[0] if infos else ()
+        rew_batch = np.array([col(i, 'env_reward') for i in infos[:T]]) if has(first, 'env_reward') else np.array(self._rew)
+        done_batch = np.array([col(i, 'env_done') for i in infos[:T]]) if has(first, 'env_done') else np.array(self._done)
+        if has(first, 'prev_level_seed'):
+            for s, e in zip(*np.nonzero(done_batch > 0)):                  # row-major: step by step, env by env, as the reference
+                info = infos[s][e]
+                self.performance_track.setdefault(info["prev_level_seed"], deque(maxlen=10)).append(info["env_reward"])
         rewards = [r for dq in self.performance_track.values() for r in dq]
         true_average_reward = np.mean(rewards) if rewards else np.nan
         return rew_batch, done_batch, true_average_reward

@@ -206,6 +206,8 @@ void launch_advnorm_merge(const double* all, int R, double* stats3, hipStream_t 
 void launch_sample(const float* hout, int n, int A, const float* u, unsigned long long seed, unsigned long long ctr,
                    int32_t* act, float* logp, float* value, hipStream_t st);
 
+void launch_philox_debug(const uint32_t* in6, int n, uint32_t* out4, float* u_out, hipStream_t st);   // test hook (mi_debug_philox)
+
 void launch_heads_sample(const float* feat, const float* Wh, const float* bh, int n, int H, int A, const float* u,
                          unsigned long long seed, unsigned long long ctr, int32_t* act, float* logp, float* value, float* pack,
                          float* hout, const float* rd, float* rew_dst, float* done_dst, hipStream_t st,

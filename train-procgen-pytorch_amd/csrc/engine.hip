@@ -478,6 +478,18 @@ void* mi_host_alloc(size_t bytes) {
     return p;
 }
 void mi_host_free(void* p) { if (p) hipHostFree(p); }
+// Page-lock caller-owned memory in place (an env's own frame buffer): mi_rollout_submit / mi_put_obs then DMA straight out of it, no
+// staging copy on the host.  Fails (-2) where the runtime refuses the range (e.g. pages already registered through another pointer).
+int mi_host_register(void* p, size_t bytes) {
+    ARG(p && bytes, "null");
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return fail(-2, "hipHostRegister refused the range"); }
+    return 0;
+}
+int mi_host_unregister(void* p) {
+    ARG(p, "null");
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return fail(-2, "hipHostUnregister failed"); }
+    return 0;
+}
 
 int mi_sync(mi_ctx* c) { ARG(c, "ctx"); JOIN(c); HIPC(hipStreamSynchronize(c->stream)); return 0; }
 
@@ -1884,6 +1896,22 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
 
 // bit 0: run rollout-sized bf16 inference passes on the separate block-2 / block-3 kernels instead of the fused launch (parity A/B)
 int mi_debug_flags(mi_ctx* c, int32_t flags) { ARG(c, "null"); JOIN(c); c->rollout_tail = !(flags & 1); c->no_pull = (flags & 4) != 0; return 0; }
+
+// Philox4x32-10 known-answer hook: n x {c0,c1,c2,c3,k0,k1} in, n x 4 output words and the n uniforms the sampler would draw
+// for (seed = k0 | k1 << 32, counter = c0 | c1 << 32) out.
+int mi_debug_philox(mi_ctx* c, const uint32_t* ctr_key6, int32_t n, uint32_t* out4, float* u_out) {
+    ARG(c && ctr_key6 && out4 && u_out, "null"); JOIN(c); ARG(n >= 1 && n <= (1 << 24), "n");
+    uint32_t *din = nullptr, *dout = nullptr; float* du = nullptr;
+    HIPC(hipMalloc((void**)&din, (size_t)n * 24)); HIPC(hipMalloc((void**)&dout, (size_t)n * 16)); HIPC(hipMalloc((void**)&du, (size_t)n * 4));
+    HIPC(hipMemcpy(din, ctr_key6, (size_t)n * 24, hipMemcpyHostToDevice));
+    launch_philox_debug(din, n, dout, du, c->stream);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpy(out4, dout, (size_t)n * 16, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(u_out, du, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(din); hipFree(dout); hipFree(du);
+    return 0;
+}
 
 // Read back what the last training-mode pass (mi_minibatch) left in the activation buffers, as fp32 NHWC: which = 8 * block + k with
 // k = 0 P0 (pooled map), 1 A1, 2 P1, 3 A2, 4 P2 (res1.conv1 out, res1 out, res2.conv1 out, block out), 5 the max-pool arg-max bytes

@@ -1137,12 +1137,34 @@ __device__ __forceinline__ void philox_round(uint32_t* c, uint32_t* k) {
     c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
     k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
 }
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): ten rounds on a 128-bit counter under a
+// 64-bit key, the key bumped by the Weyl constants between rounds (the bump after the last round is unused).  Known-answer vectors
+// of the Random123 distribution are checked through mi_debug_philox (tests/test_gpu_engine.py) and in oracle/philox.py.
+__device__ __forceinline__ void philox4x32_10(uint32_t* c, uint32_t* k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+}
 __device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr) {
     uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
     uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    philox4x32_10(c, k);
     return (float)(c[0] >> 8) * (1.0f / 16777216.0f);     // [0,1), 24 bits
+}
+// test hook: in6[i] = {c0,c1,c2,c3,k0,k1} -> out4[i] = the four output words; u_out[i] = the sampler's uniform for
+// (seed = k0 | k1 << 32, counter = c0 | c1 << 32), i.e. exactly what sample_kernel / heads_sample_kernel draw
+__global__ void philox_debug_kernel(const uint32_t* in6, int n, uint32_t* out4, float* u_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c[4] = {in6[6 * i], in6[6 * i + 1], in6[6 * i + 2], in6[6 * i + 3]};
+    uint32_t k[2] = {in6[6 * i + 4], in6[6 * i + 5]};
+    philox4x32_10(c, k);
+    for (int j = 0; j < 4; ++j) out4[4 * i + j] = c[j];
+    u_out[i] = philox_uniform((unsigned long long)in6[6 * i + 4] | ((unsigned long long)in6[6 * i + 5] << 32),
+                              (unsigned long long)in6[6 * i] | ((unsigned long long)in6[6 * i + 1] << 32));
+}
+void launch_philox_debug(const uint32_t* in6, int n, uint32_t* out4, float* u_out, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(philox_debug_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in6, n, out4, u_out);
 }
 // Rollout head, fused: policy/value heads (common/policy.py:74-80) + log-softmax + sample + log_prob
 // (agents/ppo.py:77-79); results also packed [n][3] = {act, logp, value} for ONE read-back.

@@ -37,11 +37,11 @@ def lib_path():
     return os.path.join(_HERE, "libmi355ppo.so")
 
 
-EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_param_count mi_set_params "
+EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_host_register mi_host_unregister mi_param_count mi_set_params "
            "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
            "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_rollout_groups mi_rollout_submit mi_rollout_wait mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_minibatch_multi mi_optimizer_step mi_loss_log_read mi_device_ptr "
-           "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma mi_debug_read mi_debug_flags mi_comm_unique_id mi_comm_init mi_comm_destroy mi_allreduce_arm mi_allreduce_grads mi_allreduce_buffer mi_adv_normalize_global mi_minibatch_positions").split()
+           "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma mi_debug_read mi_debug_flags mi_comm_unique_id mi_comm_init mi_comm_destroy mi_allreduce_arm mi_allreduce_grads mi_allreduce_buffer mi_adv_normalize_global mi_minibatch_positions mi_debug_philox").split()
 
 
 def load_library():
@@ -61,6 +61,8 @@ def load_library():
     lib.mi_host_free.argtypes = [C.c_void_p]
     lib.mi_host_free.restype = None
     lib.mi_profile_class_name.restype = C.c_char_p
+    lib.mi_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.mi_host_unregister.argtypes = [C.c_void_p]
     # the per-env-step entry point is called T+1 times per iteration: declared argtypes let plain ints / addresses through
     # without building ctypes wrapper objects on every call
     lib.mi_rollout_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -96,6 +98,8 @@ class Engine:
         self._chk(self.lib.mi_create(C.byref(cfg), C.byref(self._ctx)))
         self.n_params = int(self.lib.mi_param_count(self._ctx))
         self._pinned = []
+        self._registered = {}          # address -> (nbytes, array kept alive): caller buffers page-locked in place (mi_host_register)
+        self._register_refused = 0
 
     # ------------------------------------------------------------------ plumbing
     def _chk(self, rc):
@@ -107,6 +111,9 @@ class Engine:
             for p in self._pinned:
                 self.lib.mi_host_free(C.c_void_p(p))
             self._pinned = []
+            for p in list(getattr(self, "_registered", {})):
+                self.lib.mi_host_unregister(p)
+            self._registered = {}
             self.lib.mi_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -126,8 +133,34 @@ class Engine:
         if not p:
             raise EngineError("mi_host_alloc failed")
         self._pinned.append(p)
+        self._pinned_n = getattr(self, "_pinned_n", {})
+        self._pinned_n[p] = n
         buf = (C.c_char * n).from_address(p)
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    MAX_REGISTERED = 64
+
+    def dma_ready(self, arr):
+        """True if `arr` (C-contiguous numpy) can be handed to rollout_submit / put_obs as it is: memory from Engine.pinned, or
+        caller memory page-locked in place now (mi_host_register, once per buffer: an env that hands its frames out in the same few
+        buffers step after step -- Procgen's rgb buffer, a pool -- is uploaded from where it lies, with no staging copy).  False when
+        the runtime refuses the range or the env keeps producing new buffers (more than MAX_REGISTERED distinct ones): stage it."""
+        addr = arr.__array_interface__['data'][0]
+        hit = self._registered.get(addr)
+        if hit is not None:
+            return hit[0] >= arr.nbytes
+        if getattr(self, "_pinned_n", {}).get(addr, -1) >= arr.nbytes:
+            return True
+        if len(self._registered) >= self.MAX_REGISTERED or self._register_refused >= 8 or not arr.flags.c_contiguous:
+            return False
+        base = arr
+        while isinstance(getattr(base, "base", None), np.ndarray):
+            base = base.base
+        if self.lib.mi_host_register(addr, arr.nbytes) != 0:
+            self._register_refused += 1
+            return False
+        self._registered[addr] = (arr.nbytes, base)
+        return True
 
     # ------------------------------------------------------------------ parameters
     def set_params(self, flat):
@@ -247,6 +280,13 @@ class Engine:
         if rc:
             self._chk(rc)
         return out[:2 * n].view(np.int64), out[2 * n:3 * n], out[3 * n:]
+
+    def rollout_wait_into(self, group, act_addr, logp_addr, val_addr):
+        """rollout_wait writing into caller arrays (raw addresses of this group's int64 / float32 / float32 slices): the collector's
+        per-group-step call, no allocation."""
+        rc = self.lib.mi_rollout_wait(self._ctx, group, act_addr, logp_addr, val_addr)
+        if rc:
+            self._chk(rc)
 
     def predict_staged(self, obs, seed=0, counter=0, u=None):
         want = np.uint8 if self.arch == ARCH_IMPALA else np.float32
@@ -466,6 +506,13 @@ class Engine:
         """Global minibatch positions of the next minibatch()'s rows (fs_coef != 0 on several ranks, include/mi355ppo.h)."""
         g = np.ascontiguousarray(gpos, dtype=np.int32)
         self._chk(self.lib.mi_minibatch_positions(self._ctx, g.ctypes.data_as(C.c_void_p), C.c_int32(g.size)))
+
+    def debug_philox(self, ctr_key6):
+        """(n,6) uint32 {c0..c3,k0,k1} -> ((n,4) uint32 Philox4x32-10 output words, (n,) the sampler's uniforms for seed k0|k1<<32, counter c0|c1<<32)."""
+        a = np.ascontiguousarray(ctr_key6, dtype=np.uint32).reshape(-1, 6)
+        out, u = np.empty((a.shape[0], 4), np.uint32), np.empty(a.shape[0], np.float32)
+        self._chk(self.lib.mi_debug_philox(self._ctx, _fp(a), C.c_int32(a.shape[0]), _fp(out), _fp(u)))
+        return out, u
 
     def debug_flags(self, flags):
         self._chk(self.lib.mi_debug_flags(self._ctx, C.c_int32(flags)))
