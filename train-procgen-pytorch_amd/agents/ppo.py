@@ -328,7 +328,7 @@ class PPO(BaseAgent):
             if t:
                 if self.detect_nan and not (np.isfinite(val).all() and np.isfinite(logp).all()):
                     raise RuntimeError(f"Found NaN / Inf in the policy outputs of rollout step {t - 1}")
-                storage.note_stored(rew, dn, StepInfo.join(infos), hidden_state)
+                storage.note_stored(rew, dn, StepInfo.join(infos))       # (hidden-state mirror: all zeros for a non-recurrent policy, left as is)
         for g in range(G):
             wait(g, pa + 8 * sls[g].start, pl + 4 * sls[g].start, pv + 4 * sls[g].start)
         obs = np.concatenate(obs_g)
