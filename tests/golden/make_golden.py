@@ -495,6 +495,47 @@ def g10_logger():
     np.savez_compressed(os.path.join(OUT, "g10_logger.npz"), **out)
 
 
+def g11_checkpoint_structure():
+    """What the reference WRITES as model_<t>.pth (agents/ppo.py:271-276) after real optimizer steps, as structure: top-level keys, the
+    model state dict's keys / shapes / dtypes in order, the optimizer state dict's `state` (index -> step / exp_avg / exp_avg_sq with
+    shapes and dtypes) and its `param_groups` list verbatim.  Two policies: IMPALA A=15 non-recurrent, and recurrent (the GRU's four
+    tensors are in the model dict and in param_groups[0]['params'] but -- never receiving a gradient, SURVEY 8(a) A9 -- have NO
+    optimizer state).  The file is written with torch.save and read back with weights_only=True, as train.py:257-263 would."""
+    import io
+    out = {}
+    for tag, rec in (("impala", False), ("impala_rec", True)):
+        torch.manual_seed(6033)
+        policy = CategoricalPolicy(ImpalaModel(3), rec, 15)
+        policy.device = CPU
+        T, E = 4, 4
+        st = Storage((3, 64, 64), 256, T, E, CPU)
+        rng = np.random.default_rng(3)
+        frames = rng.integers(0, 256, size=(T + 1, E, 64, 64, 3), dtype=np.uint8)
+        hid = np.zeros((E, 256), np.float32)
+        for t in range(T):
+            st.store(frames_to_ref_obs(frames[t]), hid, rng.integers(0, 15, E), rng.standard_normal(E).astype(np.float32),
+                     (rng.random(E) < 0.2), [{} for _ in range(E)], np.full(E, np.log(1 / 15), np.float32), rng.standard_normal(E).astype(np.float32))
+        st.store_last(frames_to_ref_obs(frames[T]), hid, rng.standard_normal(E).astype(np.float32))
+        st.compute_estimates(0.999, 0.95, True, True)
+        agent = PPO(None, policy, _NullLogger(), st, CPU, 1, n_steps=T, n_envs=E, epoch=1, n_minibatch=2, mini_batch_size=8, learning_rate=5e-4)
+        agent.optimize()                                                     # 2 optimizer steps
+        buf = io.BytesIO()
+        torch.save({'model_state_dict': agent.policy.state_dict(), 'optimizer_state_dict': agent.optimizer.state_dict()}, buf)
+        buf.seek(0)
+        ck = torch.load(buf, map_location="cpu", weights_only=True)
+        desc = lambda v: [list(v.shape), str(v.dtype)]
+        osd = ck["optimizer_state_dict"]
+        out[tag] = {
+            "top_keys": list(ck.keys()),
+            "model": [[k, *desc(v)] for k, v in ck["model_state_dict"].items()],
+            "opt_keys": list(osd.keys()),
+            "opt_state": [[int(i), [[k, *desc(v)] for k, v in s.items()], float(s["step"])] for i, s in osd["state"].items()],
+            "param_groups": osd["param_groups"],
+            "n_parameters": len(list(agent.policy.parameters())),
+        }
+    json.dump(out, open(os.path.join(OUT, "g11_checkpoint_structure.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                      # regenerate selected fixtures only: python make_golden.py g4_feature_sparsity ...
@@ -512,3 +553,4 @@ if __name__ == "__main__":
     g10_logger(); print("G10 logger done")
     g8_recurrent(); print("G8 done")
     g9_recurrent_predict(); print("G9 done")
+    g11_checkpoint_structure(); print("G11 done")

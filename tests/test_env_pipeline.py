@@ -147,3 +147,80 @@ def test_host_cost_per_step_against_the_wrapper_chain():
     t2 = time.perf_counter()
     print(f"\nhost pipeline per step at E=256: frame source {(t1 - t0) / 5 * 1e3:.2f} ms, wrapper chain + fp32 cast {(t2 - t1) / 5 * 1e3:.2f} ms")
     assert (t1 - t0) < (t2 - t1)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 1's env
+def test_cartpole_nine_observation_layout_and_dynamics():
+    """common/env/vec_envs.py CartPoleVec = the reference's pre-vectorised cart-pole (discrete_env/cartpole_pre_vec.py:136-149,197-262;
+    pre_vec_env.py:78-118), PARITY UNPINNED (the reference class needs gymnasium code executed; no trajectory fixture exists).  Checked:
+    the 9-column observation [x, x_dot, theta, theta_dot, gravity, pole_length, cart_mass, pole_mass, force_mag]; an env's five physics
+    columns are constant within an episode and inside the constructor's ranges; every transition equals a scalar restatement of
+    Florian's equations with that env's parameters; termination beyond +-2.4 / +-12 degrees and truncation at max_steps re-draw ALL nine
+    columns of exactly the ended envs; reward 1, info[i]['env_reward'] == 1; train / validation ranges of create_cartpole and the
+    `_v` overrides of the `cartpole` hyper-parameter set."""
+    import math
+    from common.env.vec_envs import CARTPOLE_PARAM_RANGE, CartPoleVec, create_cartpole
+    E = 16
+    env = CartPoleVec(E, seed=3, max_steps=40)
+    obs = env.reset().copy()
+    assert obs.shape == (E, 9) and env.observation_space.shape == (9,) and env.action_space.n == 2
+    lo = np.array([-.05] * 4 + [9.8, 0.5, 1.0, 0.1, 10.0]); hi = np.array([.05] * 4 + [10.4, 1.0, 1.5, 0.2, 10.0])
+    assert (obs >= lo).all() and (obs <= hi).all() and len(np.unique(obs[:, 4])) == E
+    rng = np.random.default_rng(0)
+    steps_alive = np.zeros(E)
+    ended_by_fall = ended_by_time = 0
+    for t in range(300):
+        act = rng.integers(0, 2, E)
+        nxt, rew, done, info = env.step(act)
+        nxt = nxt.copy()
+        steps_alive += 1
+        for e in range(E):
+            x, xd, th, thd, g, L, mc, mp, fm = obs[e]
+            f = fm if act[e] == 1 else -fm
+            tot = mp + mc
+            temp = (f + mp * L * thd * thd * math.sin(th)) / tot
+            thacc = (g * math.sin(th) - math.cos(th) * temp) / (L * (4.0 / 3.0 - mp * math.cos(th) ** 2 / tot))
+            xacc = temp - mp * L * thacc * math.cos(th) / tot
+            want = np.array([x + 0.02 * xd, xd + 0.02 * xacc, th + 0.02 * thd, thd + 0.02 * thacc, g, L, mc, mp, fm])
+            fell = abs(want[0]) > 2.4 or abs(want[2]) > 12 * 2 * math.pi / 360
+            timed = steps_alive[e] >= 40
+            assert bool(done[e]) == (fell or timed), (t, e)
+            if done[e]:
+                ended_by_fall += fell; ended_by_time += (timed and not fell)
+                assert (nxt[e] >= lo).all() and (nxt[e] <= hi).all()                   # a fresh episode: all nine columns re-drawn
+                assert not np.array_equal(nxt[e, 4:], obs[e, 4:])
+                steps_alive[e] = 0
+            else:
+                np.testing.assert_allclose(nxt[e], want, rtol=1e-12, atol=1e-14)
+                assert np.array_equal(nxt[e, 4:], obs[e, 4:])                          # physics parameters fixed within the episode
+        assert np.array_equal(rew, np.ones(E)) and len(info) == E and info[0]["env_reward"] == 1.0 and "env_reward" in info[0]
+        obs = nxt
+    assert ended_by_fall > 5 and ended_by_time > 0
+    # same seed -> same trajectory (numpy default_rng(seed), what gymnasium's seeding.np_random(seed) builds)
+    a, b = CartPoleVec(4, seed=11), CartPoleVec(4, seed=11)
+    assert np.array_equal(a.reset(), b.reset()) and np.array_equal(a.reset(), np.random.default_rng(11).uniform(a.low, a.high, (2, 4, 9))[1])
+    # create_cartpole: second entry of every range for the validation env; `_v` hyper-parameters override it (config.yml cartpole: degrees_v 9, h_range_v 1.8)
+    hp = {"n_envs": 8, "degrees_v": 9, "h_range_v": 1.8}
+    tr, va = create_cartpole(hp, False, seed=1), create_cartpole(hp, True, seed=1)
+    assert tr.n_envs == 8 and tr.x_threshold == 2.4 and abs(tr.theta_threshold - 12 * 2 * math.pi / 360) < 1e-15
+    assert va.x_threshold == 1.8 and abs(va.theta_threshold - 9 * 2 * math.pi / 360) < 1e-15
+    assert tr.low[4] == CARTPOLE_PARAM_RANGE["min_gravity"][0] and va.low[4] == 10.4 and va.high[4] == 24.8 and va.high[5] == 2.0 and va.high[6] == 3.0
+    o = va.reset()
+    assert (o[:, 4] >= 10.4).all() and (o[:, 4] <= 24.8).all() and (o[:, 7] >= 0.2).all()
+
+
+def test_step_info_behaves_like_the_list_of_dicts():
+    """StepInfo (column-wise step info) under the uses the reference makes of a step's `info` list: len, indexing, iteration, key tests
+    on an entry, np.array(info)[mask] is replaced by column(key) / info[i]; join() over env groups keeps env order."""
+    from common.env.vec_envs import StepInfo
+    rows = [{"prev_level_seed": 7 + i, "level_complete": i % 2} for i in range(3)]
+    a = StepInfo(3, {"env_reward": np.array([1.0, 2.0, 3.0])}, rows=rows)
+    b = StepInfo(2, {"env_reward": np.array([4.0, 5.0]), "prev_level_seed": np.array([1, 2])})
+    assert len(a) == 3 and a[1] == {"prev_level_seed": 8, "level_complete": 1, "env_reward": 2.0} and "env_reward" in a[0]
+    assert a.has("prev_level_seed") and a.has("env_reward") and not a.has("env_done")
+    assert [d["env_reward"] for d in a] == [1.0, 2.0, 3.0] and a[-1]["prev_level_seed"] == 9
+    j = StepInfo.join([a, b])
+    assert len(j) == 5 and j[3]["env_reward"] == 4.0 and j[4]["prev_level_seed"] == 2 and j[0]["prev_level_seed"] == 7
+    assert np.array_equal(j.column("env_reward"), [1, 2, 3, 4, 5]) and np.array_equal(j.column("prev_level_seed"), [7, 8, 9, 1, 2])
+    plain = StepInfo.join([[{"k": 1}, {"k": 2}], [{"k": 3}]])                      # groups that speak the plain protocol
+    assert len(plain) == 3 and plain[2] == {"k": 3} and np.array_equal(plain.column("k"), [1, 2, 3])

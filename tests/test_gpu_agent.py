@@ -148,6 +148,51 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     assert np.array_equal(m1, m2) and np.array_equal(v1, v2) and agent2.optimizer.step_count == 4
 
 
+@pytest.mark.parametrize("tag,rec", [("impala", False), ("impala_rec", True)])
+def test_checkpoint_structure_equals_the_reference_written_file(tag, rec):
+    """Fixture G11 (tests/golden/g11_checkpoint_structure.json, written by make_golden.py from a checkpoint the REFERENCE's PPO saved after
+    two optimizer steps, agents/ppo.py:271-276): same top-level keys; the model state dict's keys, shapes and dtypes in the same order;
+    the optimizer state dict's `state` indices with step / exp_avg / exp_avg_sq of the same shapes and dtypes (the frozen GRU of a
+    recurrent policy: in `param_groups[0]['params']`, absent from `state`); `param_groups` equal entry for entry (lr, betas, eps, the
+    torch.optim.Adam flags).  So render.py / run_utils.py / `--model_file` of the reference read our file as they read their own."""
+    import io, json
+    from conftest import GOLD
+    from agents.ppo import PPO
+    from common.model import ImpalaModel
+    from common.policy import CategoricalPolicy
+    from common.storage import Storage
+    want = json.load(open(os.path.join(GOLD, "g11_checkpoint_structure.json")))[tag]
+    T, E = 4, 4
+    torch.manual_seed(6033)
+    policy = CategoricalPolicy(ImpalaModel(3), rec, 15)
+    storage = Storage((3, 64, 64), 256, T, E, torch.device("cuda", 0))
+    agent = PPO(None, policy, _Log(), storage, torch.device("cuda", 0), 1, n_steps=T, n_envs=E, epoch=1, n_minibatch=2, mini_batch_size=8,
+                learning_rate=5e-4)
+    rng = np.random.default_rng(3)
+    eng = agent.engine
+    from mi355 import engine as M
+    for t in range(T + 1):
+        eng.put_obs(t, rng.integers(0, 256, size=(E, 64, 64, 3), dtype=np.uint8)); eng.sync()
+    eng.write_field(M.F_ACT, rng.integers(0, 15, (T, E)).astype(np.float32)); eng.write_field(M.F_LOGP, np.full((T, E), np.log(1 / 15), np.float32))
+    eng.write_field(M.F_VALUE, rng.standard_normal((T + 1, E)).astype(np.float32)); eng.write_field(M.F_REW, rng.standard_normal((T, E)).astype(np.float32))
+    eng.write_field(M.F_DONE, (rng.random((T, E)) < 0.2).astype(np.float32))
+    storage.compute_estimates(0.999, 0.95, True, True)
+    agent.optimize()                                                         # 2 optimizer steps, as in the fixture
+    buf = io.BytesIO()
+    torch.save({'model_state_dict': policy.state_dict(), 'optimizer_state_dict': agent.optimizer.state_dict()}, buf)
+    buf.seek(0)
+    ck = torch.load(buf, map_location="cpu", weights_only=True)
+    desc = lambda v: [list(v.shape), str(v.dtype)]
+    assert list(ck.keys())[:2] == want["top_keys"]                           # (ours appends t / learning_rate / reward_norm in train(); not here)
+    assert [[k, *desc(v)] for k, v in ck["model_state_dict"].items()] == want["model"]
+    osd = ck["optimizer_state_dict"]
+    assert list(osd.keys()) == want["opt_keys"]
+    got_state = [[int(i), [[k, *desc(v)] for k, v in s_.items()], float(s_["step"])] for i, s_ in osd["state"].items()]
+    assert got_state == want["opt_state"]
+    assert osd["param_groups"] == want["param_groups"]
+    assert len(list(policy.parameters())) == want["n_parameters"]
+
+
 def test_recurrent_policy_golden_and_agent_flow():
     """C5 path: GRU cell in the rollout only (golden G9 from the reference), recurrent env-group minibatches,
     and -- like the reference -- an update that never touches the GRU."""
@@ -228,7 +273,8 @@ def test_recurrent_checkpoint_restores_the_frozen_gru():
 
 
 def test_cartpole_learns():
-    """Config C1 plumbing end to end: MLP policy + numpy cart-pole; mean episode length must grow."""
+    """Config C1 plumbing end to end: MLPModel(9, 4, 256, 64) (the `cartpole` hyper-parameter set's embedder, config.yml) + the 9-observation
+    pre-vectorised cart-pole; mean episode length must grow."""
     from agents.ppo import PPO
     from common.env.vec_envs import CartPoleVec
     from common.logger import Logger
@@ -238,9 +284,10 @@ def test_cartpole_learns():
     torch.manual_seed(0)
     E, T = 64, 64
     env = CartPoleVec(E, seed=0)
-    model = MLPModel(4, 4, 256, 64)
+    assert env.observation_space.shape == (9,)
+    model = MLPModel(9, 4, 256, 64)
     policy = CategoricalPolicy(model, False, 2)
-    storage = Storage((4,), 64, T, E, torch.device("cuda", 0))
+    storage = Storage((9,), 64, T, E, torch.device("cuda", 0))
     logger = Logger(E, None)
     agent = PPO(env, policy, logger, storage, torch.device("cuda", 0), 1, n_steps=T, n_envs=E, epoch=3, n_minibatch=4,
                 mini_batch_size=1024, gamma=0.99, lmbda=0.95, learning_rate=1e-3, entropy_coef=0.01, seed=0)
@@ -379,22 +426,30 @@ precision = sys.argv[7] if len(sys.argv) > 7 else "fp32"
 xcoef = float(sys.argv[8]) if len(sys.argv) > 8 else 0.02
 fscoef = float(sys.argv[9]) if len(sys.argv) > 9 else 0.0
 rec = len(sys.argv) > 10 and sys.argv[10] == "rec"
+T, EG, B = [int(x) for x in (sys.argv[11] if len(sys.argv) > 11 else "4,8,16").split(",")]
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+backend = os.environ.get("TWO_RANK_BACKEND", "gloo")           # "nccl": one GPU per rank (RCCL), needs world GPUs
+dev = rank if backend == "nccl" else 0
+torch.cuda.set_device(dev)
 if world > 1:
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 from agents.ppo import PPO
 from common.model import ImpalaModel
 from common.policy import CategoricalPolicy
 from common.storage import Storage
 from mi355 import engine as M
-T, EG, A = 4, 8, 15
+A = 15
 E = EG // world
 torch.manual_seed(6033)
 policy = CategoricalPolicy(ImpalaModel(3), rec, A)
-storage = Storage((3, 64, 64), 256, T, E, torch.device("cuda", 0))
+storage = Storage((3, 64, 64), 256, T, E, torch.device("cuda", dev))
 class L: episode_reward_buffer = [0.0]; logdir = "/tmp"
-agent = PPO(None, policy, L(), storage, torch.device("cuda", 0), 1, n_steps=T, n_envs=E, epoch=1, n_minibatch=1,
-            mini_batch_size=16, gamma=0.999, lmbda=0.95, learning_rate=5e-4, x_entropy_coef=xcoef, fs_coef=fscoef, precision=precision)
+agent = PPO(None, policy, L(), storage, torch.device("cuda", dev), 1, n_steps=T, n_envs=E, epoch=1, n_minibatch=1,
+            mini_batch_size=B, gamma=0.999, lmbda=0.95, learning_rate=5e-4, x_entropy_coef=xcoef, fs_coef=fscoef, precision=precision)
+assert agent._native == (backend == "nccl" and world > 1 and os.environ.get("MI355_NATIVE_COMM") == "1")
 rng = np.random.default_rng(0)
 frames = rng.integers(0, 256, size=(T + 1, EG, 64, 64, 3), dtype=np.uint8)
 act = rng.integers(0, A, (T, EG)); logp = (np.log(1 / A) + 0.2 * rng.standard_normal((T, EG))).astype(np.float32)
@@ -420,9 +475,13 @@ if rec:
 storage.compute_estimates(0.999, 0.95, True, True, agent.coll)
 adv = eng.read_field(M.F_ADV)
 torch.manual_seed(5)
+passes = []
+for nm in ("minibatch", "minibatch_multi"):
+    f = getattr(eng, nm)
+    setattr(eng, nm, (lambda f: lambda idx, *a, **k: (passes.append(len(idx)), f(idx, *a, **k))[1])(f))
 summary = agent.optimize()
 if rank == 0:
-    np.savez(out, params=eng.get_params(), adv=adv, total=summary["Loss/total"], xent=summary["Loss/x_entropy"], fs=summary["Loss/feature_sparsity"],
+    np.savez(out, params=eng.get_params(), adv=adv, passes=np.array(passes), total=summary["Loss/total"], xent=summary["Loss/x_entropy"], fs=summary["Loss/feature_sparsity"],
              logp=eng.read_field(M.F_LOGP), value=eng.read_field(M.F_VALUE), act=eng.read_field(M.F_ACT), hid=hid)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
@@ -475,6 +534,60 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, precision, xcoef, f
         subprocess.run([sys.executable, str(script), "0", "1", port, off, ROOT, PKG, precision, str(xcoef), "0.0"], check=True, env=env, timeout=300)
         assert np.abs(np.load(off)["params"] - a["params"]).max() > 1e-4
     assert np.abs(a["params"] - b["params"]).max() > 0 or True
+
+
+def test_two_ranks_c4_shaped_accumulation_of_eight_in_one_merged_pass(tmp_path):
+    """BASELINE config 4's update shape on two ranks (rehearsal on one GPU, gloo): batch_size / mini_batch_size = 8 accumulated global
+    minibatches per optimizer step (agents/ppo.py:155-177; C4: N = 524 288, 8 x 8192 between two steps), x_entropy_coef = fs_coef = 0 so
+    that every rank sends its shares of all eight through the network in ONE merged pass (mi_minibatch_multi, 8 segments), statistics
+    ring reduced once per optimize(), one gradient all-reduce: parameters after the step equal the single process's, which runs the
+    eight minibatches merged as well."""
+    script = tmp_path / "two_rank.py"
+    script.write_text(_TWO_RANK)
+    port = str(29400 + os.getpid() % 1000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = str(tmp_path / "one.npz"); two = str(tmp_path / "two.npz")
+    for precision in ("fp32", "bf16"):
+        args = [ROOT, PKG, precision, "0.0", "0.0", "", "8,8,8"]          # T = 8, 8 envs, minibatch 8: N = 64 -> accumulation 8
+        subprocess.run([sys.executable, str(script), "0", "1", port, one] + args, check=True, env=env, timeout=300)
+        procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, two] + args, env=env) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        a, b = np.load(one), np.load(two)
+        assert a["passes"].tolist() == [64] and len(b["passes"]) == 1 and 16 <= int(b["passes"][0]) <= 48      # ONE merged pass per optimizer step
+        np.testing.assert_allclose(b["adv"], a["adv"][:, :4], rtol=0, atol=2e-6)
+        assert abs(float(a["total"]) - float(b["total"])) < 1e-5
+        np.testing.assert_allclose(b["params"], a["params"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("xcoef", [0.0, 0.02])
+def test_native_rccl_equals_torch_distributed_on_two_gpus(tmp_path, xcoef):
+    """The in-library RCCL path (MI355_NATIVE_COMM=1: communicator pair behind the C ABI, gradient regions A = [embedder.fc.weight, end)
+    and B = [0, embedder.fc.weight) handed to the side stream during the backward pass, statistics / advantage collectives on the main
+    stream) against torch.distributed's RCCL process group on the aliased buffers, two ranks on two GPUs: armed native, unarmed
+    native (MI355_NATIVE_ARM=0: one all-reduce of the whole buffer at the step) and torch.distributed give BIT-equal parameters (a
+    two-rank sum is one addition per element whatever the region split), and all equal the single-process run to 2e-6."""
+    script = tmp_path / "two_rank.py"
+    script.write_text(_TWO_RANK)
+    port = str(29300 + os.getpid() % 1000)
+    one = str(tmp_path / "one.npz")
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = [ROOT, PKG, "bf16", str(xcoef), "0.0", "", "4,8,16"]
+    subprocess.run([sys.executable, str(script), "0", "1", port, one] + args, check=True, env=base, timeout=300)
+    res = {}
+    for name, extra in (("armed", dict(MI355_NATIVE_COMM="1")), ("unarmed", dict(MI355_NATIVE_COMM="1", MI355_NATIVE_ARM="0")), ("torch", {})):
+        out = str(tmp_path / f"{name}.npz")
+        env = dict(base, TWO_RANK_BACKEND="nccl", **extra)
+        procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, out] + args, env=env) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        res[name] = np.load(out)
+    a = np.load(one)
+    for name, b in res.items():
+        np.testing.assert_allclose(b["params"], a["params"], rtol=0, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(b["adv"], a["adv"][:, :4], rtol=0, atol=2e-6, err_msg=name)
+    assert np.array_equal(res["armed"]["params"], res["unarmed"]["params"]) and np.array_equal(res["armed"]["params"], res["torch"]["params"])
 
 
 _RCCL_ONE = r'''

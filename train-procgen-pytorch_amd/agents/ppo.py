@@ -100,6 +100,8 @@ class PPO(BaseAgent):
         # collectives: RCCL inside the library when the process group is "nccl" (one GPU per rank); torch.distributed on aliased
         # buffers otherwise (gloo: CPU tests / rehearsal)
         self._native = self.coll.attach_native(self.engine) if self.coll.active else False
+        import os
+        self._arm = self._native and os.environ.get("MI355_NATIVE_ARM", "1") != "0"      # (A/B switch of the overlapped exchange, tests)
         if self.coll.active:
             self.engine.set_multirank(True)
             gp, gn = self.engine.device_ptr(PTR_GRADS)
@@ -219,7 +221,7 @@ class PPO(BaseAgent):
                     eng.minibatch_positions(op[4])
                 # the LAST pass before an optimizer step hands its gradient regions to the side stream as they become final
                 # (mi_allreduce_arm); with a per-minibatch statistics exchange the backward pass runs inside minibatch_finish (below)
-                if native and nxt is not None and nxt[0] == "step":
+                if self._arm and nxt is not None and nxt[0] == "step":
                     eng.allreduce_arm()
                 if len(seg_n) > 1 or merge:
                     eng.minibatch_multi(local, seg_n, n_global, hp)
@@ -235,7 +237,7 @@ class PPO(BaseAgent):
                         coll.allreduce_sum_(self._stats_t)       # 32 floats: loss sums + mean action probabilities
                         if fs_global:
                             coll.allreduce_max_(self._fskeys_t)  # 2048 int64 (value bits, position) candidates
-                if native and nxt is not None and nxt[0] == "step":
+                if self._arm and nxt is not None and nxt[0] == "step":
                     eng.allreduce_arm()
                 eng.minibatch_finish()
             elif op[0] == "step":

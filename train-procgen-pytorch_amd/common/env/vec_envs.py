@@ -2,8 +2,8 @@
 (reset() -> obs ; step(act) -> (obs, rew, done, info) ; close()), reference:
 common/env/procgen_wrappers.py:45-124.  Rollout collection stays on the host (north_star).
 
-* CartPoleVec   -- a from-scratch numpy cart-pole (classic Barto/Sutton dynamics, Euler, tau 0.02) with
-                   auto-reset, the plumbing config C1 (MLP policy).
+* CartPoleVec   -- the reference's 9-observation pre-vectorised cart-pole (discrete_env/cartpole_pre_vec.py) restated in numpy,
+                   the plumbing config C1 (MLPModel(9, ...)).
 * SyntheticFrames -- random uint8 64x64x3 frames, N(0,1) rewards, Bernoulli(0.01) dones: the synthetic
                    learner-side workload of SURVEY 8(d) / bench.py.
 * create_procgen_env -- the real engine if the `procgen` package is importable (it is not in the build image).
@@ -71,47 +71,93 @@ class StepInfo:
 
 
 class CartPoleVec:
-    gravity, masscart, masspole, length, force_mag, tau = 9.8, 1.0, 0.1, 0.5, 10.0, 0.02
-    x_threshold, theta_threshold = 2.4, 12 * 2 * np.pi / 360
+    """The reference's pre-vectorised cart-pole (discrete_env/cartpole_pre_vec.py:20-205 on discrete_env/pre_vec_env.py:21-125),
+    restated in numpy: BASELINE config 1's env.  Observation = the 9-column state (cartpole_pre_vec.py:136-149, 197-208)
 
-    def __init__(self, n_envs, max_steps=500, seed=0):
-        self.n_envs, self.max_steps = n_envs, max_steps
+        [x, x_dot, theta, theta_dot, gravity, pole_length, cart_mass, pole_mass, force_mag]
+
+    -- the four dynamic variables plus the five physics parameters an episode was drawn with, which is why the reference builds
+    MLPModel(9, ...) for `--env_name cartpole`.  Every episode start draws all nine uniformly from [low, high] (start_space,
+    :163-171: the dynamic variables from +-0.05, the parameters from their min/max range); Florian's equations with the per-env
+    parameters, Euler steps of tau = 0.02 (:214-245); termination beyond +-h_range or +-degrees (:254-262), truncation at max_steps
+    (pre_vec_env.py:86-87); reward 1 every step; info[i] = {'env_reward': 1.0} (:112-113).  Kept from the reference: when ANY env ends,
+    a whole (n_envs, 9) block is drawn and only the ended rows take their values (pre_vec_env.py:111-118), and `done` is the
+    `terminated` array AFTER the reset.  The generator is numpy's default_rng(seed) -- what gymnasium's seeding.np_random(seed)
+    constructs (PCG64 over SeedSequence(seed)).  Parity with the reference's class is UNPINNED: it cannot be imported here without
+    stand-ins for gymnasium code it executes (spaces, Env, seeding) and the reference holds no trajectory fixture;
+    tests/test_env_pipeline.py checks the dynamics against a scalar restatement of the same equations."""
+    tau = 0.02
+
+    def __init__(self, n_envs, degrees=12, h_range=2.4, min_gravity=9.8, max_gravity=10.4, min_pole_length=0.5, max_pole_length=1.0,
+                 min_cart_mass=1.0, max_cart_mass=1.5, min_pole_mass=0.1, max_pole_mass=0.2, min_force_mag=10., max_force_mag=10.,
+                 max_steps=500, seed=0, **_ignored):
+        if n_envs < 2:
+            raise Exception("n_envs must be greater than or equal to 2")
+        self.n_envs = self.num_envs = n_envs
+        self.max_steps = max_steps
+        self.theta_threshold, self.x_threshold = degrees * 2 * np.pi / 360, h_range
+        self.low = np.array([-0.05] * 4 + [min_gravity, min_pole_length, min_cart_mass, min_pole_mass, min_force_mag])
+        self.high = np.array([0.05] * 4 + [max_gravity, max_pole_length, max_cart_mass, max_pole_mass, max_force_mag])
         self.rng = np.random.default_rng(seed)
-        self.observation_space = _Space(shape=(4,))
+        self.observation_space = _Space(shape=(9,))
         self.action_space = _Space(n=2)
-        self.state = np.zeros((n_envs, 4))
-        self.steps = np.zeros(n_envs, dtype=np.int64)
+        self.reward = np.ones(n_envs)
+        self.info = StepInfo(n_envs, {"env_reward": self.reward})
+        self.state = np.zeros((n_envs, 9))
+        self.terminated = np.full(n_envs, True)
+        self.n_steps = np.zeros(n_envs)
 
-    def _fresh(self, k):
-        return self.rng.uniform(-0.05, 0.05, size=(k, 4))
+    def _set(self):
+        fresh = self.rng.uniform(low=self.low, high=self.high, size=(self.n_envs, 9))
+        self.state[self.terminated] = fresh[self.terminated]
+        self.n_steps[self.terminated] = 0
+        return self.state
 
     def reset(self):
-        self.state = self._fresh(self.n_envs)
-        self.steps[:] = 0
-        return self.state.astype(np.float32)
+        self.terminated = np.full(self.n_envs, True)
+        self.n_steps = np.zeros(self.n_envs)
+        return self._set()
 
     def step(self, act):
-        x, xd, th, thd = self.state.T
-        force = np.where(np.asarray(act) == 1, self.force_mag, -self.force_mag)
-        total_m, pml = self.masscart + self.masspole, self.masspole * self.length
+        act = np.asarray(act)
+        assert act.size == self.n_envs and np.all(act < 2)
+        x, xd, th, thd, g, length, m_cart, m_pole, f_mag = self.state.T
+        force = np.where(act.reshape(-1) == 0, -1.0, 1.0) * f_mag
         ct, st = np.cos(th), np.sin(th)
-        temp = (force + pml * thd ** 2 * st) / total_m
-        thacc = (self.gravity * st - ct * temp) / (self.length * (4.0 / 3.0 - self.masspole * ct ** 2 / total_m))
-        xacc = temp - pml * thacc * ct / total_m
-        self.state = np.stack([x + self.tau * xd, xd + self.tau * xacc, th + self.tau * thd, thd + self.tau * thacc], axis=1)
-        self.steps += 1
-        fell = (np.abs(self.state[:, 0]) > self.x_threshold) | (np.abs(self.state[:, 2]) > self.theta_threshold)
-        done = fell | (self.steps >= self.max_steps)
-        rew = np.ones(self.n_envs, dtype=np.float32)
-        info = [{} for _ in range(self.n_envs)]
-        if done.any():
-            k = int(done.sum())
-            self.state[done] = self._fresh(k)
-            self.steps[done] = 0
-        return self.state.astype(np.float32), rew, done, info
+        pml, total = m_pole * length, m_pole + m_cart
+        temp = (force + pml * thd ** 2 * st) / total
+        thacc = (g * st - ct * temp) / (length * (4.0 / 3.0 - m_pole * ct ** 2 / total))
+        xacc = temp - pml * thacc * ct / total
+        self.state = np.vstack((x + self.tau * xd, xd + self.tau * xacc, th + self.tau * thd, thd + self.tau * thacc,
+                                g, length, m_cart, m_pole, f_mag)).T
+        nx, nth = self.state[:, 0], self.state[:, 2]
+        self.terminated = (nx < -self.x_threshold) | (nx > self.x_threshold) | (nth < -self.theta_threshold) | (nth > self.theta_threshold)
+        self.n_steps += 1
+        self.terminated[self.n_steps >= self.max_steps] = True
+        if np.any(self.terminated):
+            self._set()
+        return self.state, self.reward, self.terminated, self.info
 
     def close(self):
         pass
+
+
+# create_cartpole (discrete_env/cartpole_pre_vec.py:397-412): [training value, validation value] of every constructor argument
+CARTPOLE_PARAM_RANGE = {"degrees": [12], "h_range": [2.4], "min_gravity": [9.8, 10.4], "max_gravity": [10.4, 24.8],
+                        "min_pole_length": [0.5, 1.0], "max_pole_length": [1.0, 2.0], "min_cart_mass": [1.0, 2.], "max_cart_mass": [1.5, 3.],
+                        "min_pole_mass": [0.1, .2], "max_pole_mass": [0.2, .4], "min_force_mag": [10.], "max_force_mag": [10.]}
+
+
+def create_cartpole(hyperparameters, is_valid=False, seed=0, n_envs=None):
+    """create_cartpole / create_pre_vec / assign_env_vars (cartpole_pre_vec.py:397-412, pre_vec_env.py:207-223, helper_pre_vec.py:52-66):
+    the validation env draws its physics from the SECOND value of every range (heavier, longer, stronger gravity); a hyper-parameter
+    `<name>` (training) or `<name>_v` (validation) overrides a range entry (config.yml `cartpole`: degrees_v 9, h_range_v 1.8);
+    max_steps may come from the hyper-parameters too."""
+    suffix, i = ("_v", -1) if is_valid else ("", 0)
+    kw = {k: hyperparameters.get(k + suffix, v[i]) for k, v in CARTPOLE_PARAM_RANGE.items()}
+    if "max_steps" in hyperparameters:
+        kw["max_steps"] = hyperparameters["max_steps"]
+    return CartPoleVec(n_envs if n_envs is not None else hyperparameters.get("n_envs", 32), seed=seed, **kw)
 
 
 class SyntheticFrames:

@@ -22,6 +22,7 @@
 // loop; the four waves are summed through LDS in a fixed order and every workgroup writes one
 // slab, which reduce_slabs adds up in a fixed order (bitwise reproducible, no float atomics).
 #include "common.h"
+#include <mutex>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -521,8 +522,8 @@ static int work_items(int n) { return (C::NIMG > 1) ? (n + C::NIMG - 1) / C::NIM
 
 template <class C>
 static void launch_fwd_t(const ConvArgs& a, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); });
     int grid = work_items<C>(a.n);
     if (grid > max_blocks<C>()) grid = max_blocks<C>();
     if (grid < 1) return;
@@ -531,8 +532,8 @@ static void launch_fwd_t(const ConvArgs& a, hipStream_t st) {
 
 template <class C>
 static void launch_wg_t(const WgradArgs& a, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); });
     int grid = work_items<C>(a.n);
     if (grid > max_blocks<C>()) grid = max_blocks<C>();
     if (grid < 1) return;

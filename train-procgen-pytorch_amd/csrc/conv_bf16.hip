@@ -9,6 +9,7 @@
 // (lane quarter kq owns channels 8kq..8kq+7); for 16 input channels it is two taps (kq>>1 selects the tap,
 // kq&1 the 8-channel half), the 10th "tap" being a zero column of the filter bank.
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 
 static int c1_grid(int n);          // persistent grid of the block1.conv weight-gradient kernel (defined with it)
@@ -573,8 +574,8 @@ __global__ __launch_bounds__(512, 4) void block2_conv_bwd_bf16_kernel(ConvArgs a
 }
 static int b2bwd_grid(int n) { return n > 512 ? 512 : n; }      // whole images per workgroup, two workgroups per CU
 static void launch_block2_conv_bwd(const ConvArgs& a, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)block2_conv_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2Bwd::LDS); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)block2_conv_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2Bwd::LDS); });
     const int grid = b2bwd_grid(a.n);
     if (grid < 1) return;
     hipLaunchKernelGGL(block2_conv_bwd_bf16_kernel, dim3(grid), dim3(B2Bwd::NT), B2Bwd::LDS, st, a);
@@ -925,10 +926,10 @@ static int wb_grid(int n) {
 }
 template <class C, bool POOLED = false>
 static void launch_wb_t(const WgradArgs& a, hipStream_t st) {
-    static bool attr = false;
+    static std::once_flag attr;
     constexpr size_t TILE = C::TILE_BYTES + (POOLED ? PoolStage<C::COUT, C::HW / 2, C::TH / 2 + 1>::BYTES : 0);
     constexpr size_t LDS = TILE > C::RED_BYTES ? TILE : C::RED_BYTES;
-    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<C, POOLED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<C, POOLED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); });
     const int grid = wb_grid<C>(a.n);
     if (grid < 1) return;
     hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<C, POOLED>), dim3(grid), dim3(256), LDS, st, a);
@@ -1404,12 +1405,11 @@ void launch_conv1_fwd_bf16(const ConvArgs& a, const unsigned short* lut16, hipSt
     hipLaunchKernelGGL(conv1_fwd_bf16_kernel, dim3(grid), dim3(256), 0, st, a, lut16);
 }
 void launch_conv1_wgrad_bf16(const WgradArgs& a, const unsigned short* lut16, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [] {
         hipFuncSetAttribute((const void*)conv1_wgrad_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_WG_LDS);
         hipFuncSetAttribute((const void*)conv1_wgrad_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_WGP_LDS);
-        attr = true;
-    }
+    });
     const int grid = c1_grid(a.n);
     if (grid < 1) return;
     if (a.pool_arg) hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<true>, dim3(grid), dim3(256), C1_WGP_LDS, st, a, lut16);
@@ -1438,9 +1438,9 @@ static int bf_grid(int n) {
 }
 template <class C, bool POOLIN = false>
 static void launch_bf_t(const ConvArgs& a, hipStream_t st) {
-    static bool attr = false;
+    static std::once_flag attr;
     constexpr size_t LDS = bf_lds_bytes<C, POOLIN>();
-    if (!attr) { hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<C, POOLIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<C, POOLIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); });
     int bpc = (int)((160 * 1024) / LDS);
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
     int grid = (C::NIMG > 1) ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;

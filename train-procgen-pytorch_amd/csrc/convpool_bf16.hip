@@ -7,6 +7,7 @@
 // backward: the gradient of the conv output is never materialised either.  PoolStage (conv_bf16.hip) rebuilds any window of it
 //           in LDS from (pooled gradient, arg-max bytes) for the conv's weight-gradient and data-gradient kernels.
 #include "common.h"
+#include <mutex>
 #include <math.h>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -297,16 +298,16 @@ template <class C>
 static void launch_cp_t(const ConvArgs& a, void* p_out, uint8_t* p_arg, hipStream_t st) {
     if (a.n >= 1024 && CP_ROLL) {                           // update-sized: whole images per workgroup, rolling conv rows
         using R = CpRoll<C>;
-        static bool attr_r = false;
-        if (!attr_r) { hipFuncSetAttribute((const void*)conv_pool_fwd_roll_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_BYTES); attr_r = true; }
+        static std::once_flag attr_r;          // (launchers run on up to 4 group worker threads)
+        std::call_once(attr_r, [] { hipFuncSetAttribute((const void*)conv_pool_fwd_roll_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_BYTES); });
         int bpc = (int)((160 * 1024) / R::LDS_BYTES);
         bpc = bpc < 1 ? 1 : (bpc > 3 ? 3 : bpc);
         const int grid = a.n > 256 * bpc ? 256 * bpc : a.n;
         hipLaunchKernelGGL(conv_pool_fwd_roll_bf16_kernel<C>, dim3(grid), dim3(256), R::LDS_BYTES, st, a, (unsigned short*)p_out, p_arg);
         return;
     }
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)conv_pool_fwd_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)conv_pool_fwd_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); });
     int bpc = (int)((160 * 1024) / C::LDS_BYTES);
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
     int grid = a.n * C::IPI;

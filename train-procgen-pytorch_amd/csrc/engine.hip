@@ -47,9 +47,11 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 #define ARG(c, msg) do { if (!(c)) return fail(-1, std::string("invalid argument: ") + msg); } while (0)
 #define NETCHK(c) do { if (const char* lf_ = mi_launch_failed_take()) return fail(-4, lf_);                                   \
-                       if (!(c)->net_err.empty()) { std::string m_ = (c)->net_err; (c)->net_err.clear(); return fail(-4, m_); } } while (0)
+                       std::string m_ = net_err_take(c); if (!m_.empty()) return fail(-4, m_); } while (0)
 
 struct mi_ctx;
+static std::string net_err_take(mi_ctx* c);                 // (the network program also runs on the env-group worker threads: guarded)
+static void net_err_set(mi_ctx* c, const std::string& m);
 static int join_groups(mi_ctx* c);
 extern "C" int mi_comm_destroy(mi_ctx* c);
 // every entry point that issues work on the context's main stream first orders it behind the env-group streams of a pipelined rollout
@@ -168,9 +170,9 @@ struct mi_ctx {
     // the global minibatch positions of the pending pass's rows (mi_minibatch_positions)
     long long *fs_keys, *fs_keys_local; int32_t *d_gpos, *h_gpos; int gpos_n; bool fs_global_pending, fs_global_apply;
     // data-parallel collectives (RCCL over xGMI), SURVEY 8(e): one communicator per context, a side stream for the gradient all-reduce
-    ncclComm_t comm; int comm_world, comm_rank; hipStream_t comm_stream; hipEvent_t ev_ar_ready, ev_ar_done;
+    ncclComm_t comm, comm_grad; int comm_world, comm_rank; hipStream_t comm_stream; hipEvent_t ev_ar_ready, ev_ar_done;   // comm: main-stream collectives; comm_grad: the side stream's
     bool ar_armed, ar_issued, ar_inflight; double* adv_all;
-    std::string net_err;        // set by the (void) network program on an unsupported launch; every entry point reports it as -4
+    std::string net_err; std::mutex net_err_mu;   // set by the (void) network program on an unsupported launch (any thread); every entry point reports it as -4
 };
 
 // ------------------------------------------------------------------------------------------ layout tables
@@ -179,6 +181,9 @@ static void add_tensor(mi_ctx* c, const std::string& name, int64_t n, int kind, 
     c->tensors.push_back(t);
     ref += n;
 }
+
+static std::string net_err_take(mi_ctx* c) { std::lock_guard<std::mutex> lk(c->net_err_mu); std::string m; m.swap(c->net_err); return m; }
+static void net_err_set(mi_ctx* c, const std::string& m) { std::lock_guard<std::mutex> lk(c->net_err_mu); if (c->net_err.empty()) c->net_err = m; }
 
 static void build_impala_layout(mi_ctx* c) {
     // reference order = policy.parameters(): embedder.block{1,2,3}.{conv,res1.conv1,res1.conv2,res2.conv1,res2.conv2}.{weight,bias},
@@ -211,6 +216,13 @@ static void build_impala_layout(mi_ctx* c) {
     add_tensor(c, "fc_value.weight", c->H, K_PLAIN, 0, 0, ref, c->wh_off + (int64_t)c->A * c->H);
     add_tensor(c, "fc_value.bias", 1, K_PLAIN, 0, 0, ref, c->bh_off + c->A);
     c->n_params = ref;
+}
+// The armed gradient exchange splits the flat gradient at embedder.fc.weight: region B = [0, fc.w_off) must hold exactly the conv
+// layers, region A = [fc.w_off, n_params) the fc layer and the heads (net_backward).  Checked once per context.
+static bool impala_regions_ok(const mi_ctx* c) {
+    for (const ConvLayer& L : c->convs)
+        if (L.w_off < 0 || L.b_off <= L.w_off || L.b_off + L.cout > c->fc.w_off) return false;
+    return c->fc.w_off < c->fc.b_off && c->fc.b_off + c->H <= c->wh_off && c->wh_off < c->bh_off && c->bh_off + c->A + 1 == c->n_params;
 }
 
 static void build_mlp_layout(mi_ctx* c) {
@@ -307,6 +319,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     if (cfg->arch == MI_ARCH_IMPALA) build_impala_layout(c); else build_mlp_layout(c);
+    if (cfg->arch == MI_ARCH_IMPALA && !impala_regions_ok(c)) { delete c; return fail(-1, "internal: parameter layout does not split at embedder.fc.weight"); }
 
     const int64_t P = c->n_params, T = c->T, E = c->E, NB = c->NB;
     HIPC(dalloc(&c->params, P)); HIPC(dalloc(&c->grads, P)); HIPC(dalloc(&c->adam_m, P)); HIPC(dalloc(&c->adam_v, P));
@@ -399,7 +412,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->h_f_floats = (size_t)4 * (E > 64 ? E : 64);
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
-    c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stream = nullptr; c->ev_ar_ready = c->ev_ar_done = nullptr;
+    c->comm = nullptr; c->comm_grad = nullptr; c->comm_world = 1; c->comm_rank = 0; c->comm_stream = nullptr; c->ev_ar_ready = c->ev_ar_done = nullptr;
     c->ar_armed = c->ar_issued = c->ar_inflight = false; c->adv_all = nullptr;
     c->fs_grad_coef = 0.f; c->fs_G = 0; c->rollout_tail = true; c->no_pull = false; c->copy_rate_bytes_per_us = getenv("MI355_COPY_GBPS") ? atof(getenv("MI355_COPY_GBPS")) * 1000.0 : 40000.0;
     if (cfg->arch != MI_ARCH_IMPALA) { c->fs_colmax = nullptr; c->fs_arg = nullptr; c->fs_keys = c->fs_keys_local = nullptr; c->d_gpos = nullptr; c->h_gpos = nullptr; }
@@ -681,7 +694,7 @@ static void conv_wgrad(mi_ctx* c, const ConvLayer& L, const void* in, const Inpu
     a.lut16 = c->bf ? c->lut16 : nullptr;
     const int grid = wgrad_grid_for(L.shape, n, c->bf);
     if (grid < 1) return;
-    if (grid > 1024) { c->net_err = "weight-gradient launch needs more than the 1024 slabs a layer owns"; return; }
+    if (grid > 1024) { net_err_set(c, "weight-gradient launch needs more than the 1024 slabs a layer owns"); return; }
     const double px = (double)n * L.hw * L.hw;
     { // SURVEY 8(d) layer-boundary bytes; block1.conv from the pooled gradient also carries the max-pool backward (p + 2X)
       const double pool_b = (pool_arg && L.cin == 3) ? c->es * (px / 4 * L.cout + 2.0 * px * L.cout) : 0.0;
@@ -699,8 +712,8 @@ static void issue_grad_allreduce(mi_ctx* c, int64_t off, int64_t n, bool last) {
     if (!c->ar_armed || !c->comm || n <= 0) return;
     hipEventRecord(c->ev_ar_ready, CUR(c));
     hipStreamWaitEvent(c->comm_stream, c->ev_ar_ready, 0);
-    ncclResult_t r = ncclAllReduce(c->grads + off, c->grads + off, (size_t)n, ncclFloat, ncclSum, c->comm, c->comm_stream);
-    if (r != ncclSuccess) { c->net_err = std::string("ncclAllReduce (gradients): ") + ncclGetErrorString(r); return; }
+    ncclResult_t r = ncclAllReduce(c->grads + off, c->grads + off, (size_t)n, ncclFloat, ncclSum, c->comm_grad, c->comm_stream);
+    if (r != ncclSuccess) { net_err_set(c, std::string("ncclAllReduce (gradients): ") + ncclGetErrorString(r)); return; }
     if (last) { hipEventRecord(c->ev_ar_done, c->comm_stream); c->ar_armed = false; c->ar_issued = true; c->ar_inflight = true; }
 }
 
@@ -820,7 +833,7 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
                 a.in = prev; a.bias = c->params + L[0].b_off; a.n = n; a.bf16 = 1; a.wbank = c->banks + L[0].bank_f;
                 const double px = (double)n * L[0].hw * L[0].hw;
                 ProfScope ps(c, PC_CONV_FWD + (int)L[0].shape, n, 2.0 * (px * L[0].cin + 2.0 * px * L[0].cout + px / 4 * L[0].cout), px * 18.0 * L[0].cin * L[0].cout);      // 8(d): I + 2X + p
-                if (!launch_conv_pool_fwd_bf16(L[0].shape, a, k.P0, k.PI, CUR(c))) { c->net_err = "no fused conv+pool kernel for this conv shape"; return; }
+                if (!launch_conv_pool_fwd_bf16(L[0].shape, a, k.P0, k.PI, CUR(c))) { net_err_set(c, "no fused conv+pool kernel for this conv shape"); return; }
             } else {
             if (b == 0) conv_fwd(c, L[0], nullptr, &src, 0, nullptr, k.C, n);
             else conv_fwd(c, L[0], prev, nullptr, 0, nullptr, k.C, n);
@@ -1603,6 +1616,11 @@ int mi_comm_init(mi_ctx* c, const void* id_bytes, size_t bytes, int32_t rank, in
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
     NCCLC(ncclCommInitRank(&c->comm, world, id, rank));
+    // The gradient regions travel on a side stream while the main stream may issue its own collectives (loss statistics, feature-
+    // sparsity keys, advantage statistics).  One communicator driven from two streams has no defined order between the two streams'
+    // operations; each stream therefore owns a communicator.  Both are used in the same host order on every rank (the update schedule
+    // is rank-uniform: mi355/dist.py update_plan), which is what RCCL needs of two communicators on one device.
+    NCCLC(ncclCommSplit(c->comm, 0, rank, &c->comm_grad, nullptr));
     c->comm_world = world; c->comm_rank = rank;
     HIPC(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     HIPC(hipEventCreateWithFlags(&c->ev_ar_ready, hipEventDisableTiming));
@@ -1613,6 +1631,7 @@ int mi_comm_init(mi_ctx* c, const void* id_bytes, size_t bytes, int32_t rank, in
 int mi_comm_destroy(mi_ctx* c) {
     if (!c || !c->comm) return 0;
     hipStreamSynchronize(c->comm_stream); hipStreamSynchronize(c->stream);
+    if (c->comm_grad) { ncclCommDestroy(c->comm_grad); c->comm_grad = nullptr; }
     ncclCommDestroy(c->comm); c->comm = nullptr;
     hipStreamDestroy(c->comm_stream); hipEventDestroy(c->ev_ar_ready); hipEventDestroy(c->ev_ar_done);
     hipFree(c->adv_all); c->adv_all = nullptr; c->comm_world = 1; c->comm_rank = 0;

@@ -6,6 +6,7 @@
 //   TN kernel : gW[M][N] += A[K][M]^T * relu(B[K][N])   (weight gradient; both operands K(=batch)-major in memory ->
 //               ds_read_b64_tr_b16 fragments; split over the batch, slabs summed in fixed order)
 #include "common.h"
+#include <mutex>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -146,8 +147,8 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs g) {
 template <bool A_F32, int TM>
 static void launch_fc_nt_t(const FcNtArgs& g, hipStream_t st) {
     constexpr size_t LDS = (size_t)(TM + 64) * NT_LD * 2;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)fc_nt_kernel<A_F32, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)fc_nt_kernel<A_F32, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); });
     hipLaunchKernelGGL((fc_nt_kernel<A_F32, TM>), dim3((g.N + 63) / 64, (g.M + TM - 1) / TM), dim3(256), LDS, st, g);
 }
 void launch_fc_nt(const FcNtArgs& g, hipStream_t st) {          // K % 128 == 0 (2048 forward, 256 data gradient)
@@ -270,8 +271,8 @@ void launch_fc_tn(const float* A, const unsigned short* B, float* gW, float* ws,
     const int k_chunk = ((K + split - 1) / split + TN_BK - 1) / TN_BK * TN_BK;
     split = (K + k_chunk - 1) / k_chunk;
     constexpr size_t LDS = (size_t)TN_BK * (TN_LDA + TN_LDB) * 2;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)fc_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)fc_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); });
     hipLaunchKernelGGL(fc_tn_kernel, dim3(N / 128, M / 64, split), dim3(256), LDS, st, A, B, ws, M, N, K, k_chunk);
     const long long total = (long long)M * N;
     hipLaunchKernelGGL(fc_tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)ws, split, total, gW);
@@ -337,8 +338,8 @@ __global__ __launch_bounds__(256) void fc_fwd_bf16_kernel(const unsigned short* 
 // embedder.fc: y[n][256] = relu(relu(x)[n][2048] * W^T + b)
 void launch_fc_fwd_bf16(const void* x_bf16, const unsigned short* wp, const float* bias, float* y, int n, hipStream_t st) {
     if (n > 0 && n % 64 == 0 && bias) {
-        static bool attr = false;
-        if (!attr) { hipFuncSetAttribute((const void*)fc_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_LDS); attr = true; }
+        static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+        std::call_once(attr, [] { hipFuncSetAttribute((const void*)fc_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_LDS); });
         hipLaunchKernelGGL(fc_fwd_bf16_kernel, dim3(4 * (n / 64)), dim3(256), FF_LDS, st, (const unsigned short*)x_bf16, wp, bias, y, n / 64);
         return;
     }
@@ -455,8 +456,8 @@ __global__ __launch_bounds__(256) void fc_dgrad_bf16_kernel(const float* __restr
 // dx[n][2048] (bf16) = (dy[n][256] * W) * (x > 0)
 void launch_fc_dgrad_bf16(const float* dy, const unsigned short* wt, const void* mask_bf16, void* dx_bf16, int n, hipStream_t st) {
     if (n > 0 && n % 128 == 0 && mask_bf16) {
-        static bool attr = false;
-        if (!attr) { hipFuncSetAttribute((const void*)fc_dgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FD_LDS); attr = true; }
+        static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+        std::call_once(attr, [] { hipFuncSetAttribute((const void*)fc_dgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FD_LDS); });
         hipLaunchKernelGGL(fc_dgrad_bf16_kernel, dim3(2048 / (64 * FD_STEPS) * (n / 128)), dim3(256), FD_LDS, st, dy, wt, (const unsigned short*)mask_bf16, (unsigned short*)dx_bf16, n / 128);
         return;
     }

@@ -13,6 +13,7 @@
 // MFMA operand order as in conv_bf16.hip: filter rows = A, pixels = B, so a lane owns 4 consecutive channels of a
 // pixel and every global / LDS access of the epilogues is an 8-byte word.
 #include "common.h"
+#include <mutex>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
@@ -279,8 +280,8 @@ using RB_32_8S = RbCfg<32,  8,  8, 1>;      // rollout-sized batches: one image 
 
 template <class C, bool BWD = false>
 static void launch_rb_t(const ResblockArgs& a, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)resblock_bf16_kernel<C, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_bf16_kernel<C, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); });
     int bpc = (int)((160 * 1024) / C::LDS_BYTES);
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
     int grid = C::WHOLE ? (a.n + C::NIMG - 1) / C::NIMG : a.n * C::TPI;
@@ -455,8 +456,8 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
 template <class C>
 static void launch_rbp_t(const ResblockPairArgs& a, hipStream_t st) {
     constexpr size_t LDS = (size_t)(C::X_ELEMS + C::Y_ELEMS + 4 * C::W_ELEMS) * 2 + 4 * C::C * 4;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)resblock_pair_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_pair_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); });
     int bpc = (int)((160 * 1024) / LDS);
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
     int grid = (a.n + C::NIMG - 1) / C::NIMG;
@@ -702,8 +703,8 @@ int resblock_bwd_full_grid(int n) {
 // 16-channel residual blocks @32x32 only (CS_16_16_32).  slab2 / slab1: [grid][2320] floats each (grid = resblock_bwd_full_grid(n)).
 void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
                                    const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)resblock_bwd_full_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbFull::LDS_BYTES); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_bwd_full_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbFull::LDS_BYTES); });
     const int grid = resblock_bwd_full_grid(n);
     if (grid < 1) return;
     RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
@@ -1188,8 +1189,8 @@ static int rb_full32s_grid(int n);
 int resblock_bwd_full32_grid(ConvShape s, int n) { return s == CS_32_32_16 ? (RB32_SPECIALISED ? rb_full32s_grid(n) : rb_full32_grid_t<RbFull32>(n)) : s == CS_32_32_8 ? rb_full32_grid_t<RbFull32S>(n) : -1; }
 template <class C>
 static void launch_rb_full32_t(const RbFullArgs& a, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)resblock_bwd_full32_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_bwd_full32_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); });
     const int grid = rb_full32_grid_t<C>(a.n);
     if (grid < 1) return;
     hipLaunchKernelGGL(resblock_bwd_full32_bf16_kernel<C>, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, a);
@@ -1201,8 +1202,8 @@ static int rb_full32s_grid(int n) { const int w = n * RbFull32W::TPI; return w >
 static void launch_rb_full32s(const RbFullArgs& a, hipStream_t st) {
     using C = RbFull32W;
     constexpr size_t LDS = (size_t)(C::X_ELEMS + 3 * C::Y_ELEMS) * 2;          // no bank copies in LDS
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)resblock_bwd_full32s_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_bwd_full32s_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); });
     const int grid = rb_full32s_grid(a.n);
     if (grid < 1) return;
     hipLaunchKernelGGL(resblock_bwd_full32s_bf16_kernel<C>, dim3(grid), dim3(512), LDS, st, a);

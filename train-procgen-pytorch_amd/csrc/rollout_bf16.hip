@@ -14,6 +14,7 @@
 // pool; conv1 output and block output -> bf16), same first-maximum pooling on order-preserving keys -- the outputs are bit-identical
 // (tests/test_gpu_bf16.py::test_fused_rollout_tail_equals_the_four_launches).  Inference only: nothing but the block-3 output is stored.
 #include "common.h"
+#include <mutex>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short rt_s16x2 __attribute__((ext_vector_type(2)));
@@ -338,8 +339,8 @@ __global__ __launch_bounds__(rt::NT) void rollout_tail_bf16_kernel(RolloutTailAr
 // x: block1 output [n][32][32][16] bf16; y: block3 output [n][8][8][32] bf16; bank / bias: the ten convs of blocks 2 and 3 in network order
 void launch_rollout_tail_bf16(const void* x, void* y, int n, const unsigned short* const* bank, const float* const* bias, hipStream_t st) {
     if (n <= 0) return;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)rollout_tail_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rt::LDS_ELEMS * 2); attr = true; }
+    static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)rollout_tail_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rt::LDS_ELEMS * 2); });
     RolloutTailArgs a{};
     a.x = (const unsigned short*)x; a.y = (unsigned short*)y; a.n = n;
     for (int k = 0; k < 10; ++k) { a.bank[k] = bank[k]; a.bias[k] = bias[k]; }

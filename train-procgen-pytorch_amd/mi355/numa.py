@@ -42,4 +42,14 @@ def pin_to_gpu_node(device_index=0, min_cpus=8):
         os.sched_setaffinity(0, want)
     except OSError:
         return None
+    # sched_setaffinity(0, ...) moves the CALLING thread only; threads that already exist (torch's intra-op pool, a process group's
+    # watchdog started by init_process_group) keep their masks: apply it to every thread of the process
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), want)
+            except OSError:
+                pass
+    except OSError:
+        pass
     return want

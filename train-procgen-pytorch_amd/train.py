@@ -30,7 +30,7 @@ import torch
 import yaml
 
 from agents.ppo import PPO
-from common.env.vec_envs import CartPoleVec, EnvGroups, SyntheticFrames, create_procgen_env
+from common.env.vec_envs import EnvGroups, SyntheticFrames, create_cartpole, create_procgen_env
 from common.logger import Logger
 from common.misc_util import set_global_seeds
 from common.model import ImpalaModel, MLPModel
@@ -133,15 +133,18 @@ def create_logdir_train(model_file, env_name, exp_name, seed, rank_suffix=""):
     """train.py:273-300.  -> (logdir, model_file): with 'auto' the one run directory that holds checkpoints and its newest model_<t>.pth."""
     logdir = os.path.join('logs', 'train', env_name, exp_name)
     if model_file == "auto":
+        is_ckpt = lambda f: f.startswith("model_") and f.endswith(".pth") and f[6:-4].isdigit()
         runs = [os.path.join(logdir, d) for d in os.listdir(logdir)] if os.path.isdir(logdir) else []
-        with_model = [d for d in runs if os.path.isdir(d) and any('model' in f for f in os.listdir(d))]
+        with_model = [d for d in runs if os.path.isdir(d) and any(is_ckpt(f) for f in os.listdir(d))]
         if len(with_model) > 1:
             raise ValueError(f"Received args.model_file = 'auto', but there are multiple experiments with saved models under experiment_name {exp_name}.")
         if len(with_model) == 0:
             raise ValueError(f"Received args.model_file = 'auto', but there are no saved models under experiment_name {exp_name}.")
         logdir = with_model[0]                                       # reuse logdir
-        files = [f for f in os.listdir(logdir) if f.startswith("model_") and f.endswith(".pth")]
+        files = [f for f in os.listdir(logdir) if is_ckpt(f)]
         model_file = os.path.join(logdir, max(files, key=lambda f: int(f[6:-4])))
+        if rank_suffix:                                               # only rank 0 writes checkpoints: the other ranks load rank 0's file
+            logdir = logdir + rank_suffix                             # but log into a sibling directory of their own
     else:
         logdir = os.path.join(logdir, time.strftime("%Y-%m-%d__%H-%M-%S") + f'__seed_{seed}' + rank_suffix)
     os.makedirs(logdir, exist_ok=True)
@@ -154,7 +157,7 @@ def _one_env(env_name, n_envs, seed, A, args, hp, is_valid, ret_rms=None, num_th
     if env_name.startswith("cartpole") or env_name == "mountain_car":
         if env_name == "mountain_car":
             raise NotImplementedError("mountain_car: only the cart-pole numpy env is built on the host side")
-        return CartPoleVec(n_envs, seed=seed)
+        return create_cartpole(hp, is_valid, seed=seed, n_envs=n_envs)        # 9 observations -> MLPModel(9, ...), BASELINE config 1
     return create_procgen_env(env_name=env_name, n_envs=n_envs, is_valid=is_valid, val_env_name=args.val_env_name,
                               start_level=args.start_level, num_levels=args.num_levels, distribution_mode=args.distribution_mode,
                               num_threads=num_threads or args.num_threads, paint_vel_info=hp.get("paint_vel_info", args.paint_vel_info),
@@ -168,6 +171,8 @@ def make_env(env_name, n_envs, seed, A, args, hp, is_valid=False):
     (EnvGroups): same protocol outwards, and the agent pipelines the groups.  Procgen groups share ONE running return variance, so
     reward normalisation stays a single statistic over all envs (procgen_wrappers.py:316-355)."""
     G = int(getattr(args, "rollout_groups", 1))
+    if G > 4:
+        raise ValueError(f"--rollout_groups {G}: the engine pipelines at most 4 env groups (mi_rollout_groups; more busy streams than that serialise)")
     if G <= 0:
         G = 4 if n_envs >= 128 and n_envs % 8 == 0 else 2
     if G == 1 or hp.get("recurrent", False) or n_envs % G or (n_envs // G) % 2 or env_name.startswith("cartpole"):
@@ -229,7 +234,7 @@ def train_ppo(args):
     A = (9 if args.reduce_duplicate_actions else 15) if hp.get("architecture", "impala") == "impala" else 2
     env = make_env(env_name, n_envs, args.seed + 2 * rank, A, args, hp)
     env_valid = make_env(env_name, n_envs, args.seed + 2 * rank + 1, A, args, hp, is_valid=True) if args.use_valid_env else None
-    logdir, model_file = create_logdir_train(args.model_file, env_name, args.exp_name, args.seed, f'__rank_{rank}' if world > 1 else '')
+    logdir, model_file = create_logdir_train(args.model_file, env_name, args.exp_name, args.seed, f'__rank_{rank}' if world > 1 and rank > 0 else '')
     np.save(os.path.join(logdir, "hyperparameters.npy"), hp)
     print(f'Logging to {logdir}')
     cfg = dict(vars(args)); cfg.update(hp)
