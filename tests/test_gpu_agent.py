@@ -189,7 +189,8 @@ def test_checkpoint_structure_equals_the_reference_written_file(tag, rec):
     assert list(osd.keys()) == want["opt_keys"]
     got_state = [[int(i), [[k, *desc(v)] for k, v in s_.items()], float(s_["step"])] for i, s_ in osd["state"].items()]
     assert got_state == want["opt_state"]
-    assert osd["param_groups"] == want["param_groups"]
+    assert json.loads(json.dumps(osd["param_groups"])) == want["param_groups"]       # (JSON: the betas tuple is a list in the fixture)
+    assert list(osd["param_groups"][0].keys()) == list(want["param_groups"][0].keys())
     assert len(list(policy.parameters())) == want["n_parameters"]
 
 
