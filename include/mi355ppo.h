@@ -68,6 +68,9 @@ int   mi_host_unregister(void* p);
 int64_t mi_param_count(mi_ctx* ctx);
 int mi_set_params(mi_ctx* ctx, const float* flat, int64_t n);
 int mi_get_params(mi_ctx* ctx, float* flat, int64_t n);
+/* dst's parameters := src's, device to device in stream order (same architecture, sizes and device): how the validation rollouts'
+ * inference-only twin context follows the trained policy (agents/ppo.py:241-252 use one policy object for both env sets) */
+int mi_copy_params(mi_ctx* dst, mi_ctx* src);
 int mi_get_grads(mi_ctx* ctx, float* flat, int64_t n);                     /* accumulated, un-clipped */
 int mi_set_adam_state(mi_ctx* ctx, const float* exp_avg, const float* exp_avg_sq, int64_t n);
 int mi_get_adam_state(mi_ctx* ctx, float* exp_avg, float* exp_avg_sq, int64_t n);

@@ -393,6 +393,39 @@ def test_policy_step_sampling():
     eng.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_copy_params_device_to_device(precision):
+    """mi_copy_params: the validation twin takes the trained context's parameters without a host round trip -- same flat vector, and its
+    next pass runs on them (bf16: the packed filter images are rebuilt), also when the twin already has env-group streams."""
+    from mi355 import layout
+    from mi355.engine import Engine
+    T, E, A = 2, 8, 15
+    rng = np.random.default_rng(2)
+    frames = rng.integers(0, 256, size=(E, 64, 64, 3), dtype=np.uint8)
+    flat = layout.flatten(shapes_for("impala", A), golden_params("impala"))
+    src = Engine("impala", T, E, A, 16, precision=precision); dst = Engine("impala", T, E, A, E, precision=precision)
+    src.set_params(flat); dst.set_params(flat * 0.5)
+    dst.rollout_groups(2)
+    before = dst.forward(frames)[0]
+    # an optimizer step on src, then the hand-over in stream order
+    for t in range(T + 1):
+        src.put_obs(t, frames)
+    src.policy_step(0, seed=1); src.policy_step(1, seed=1); src.policy_step(2, seed=1)
+    src.put_step(0, np.ones(E, np.float32), np.zeros(E, np.float32)); src.put_step(1, np.ones(E, np.float32), np.zeros(E, np.float32))
+    src.compute_estimates(0.99, 0.95, True, True)
+    src.minibatch(np.arange(16), 16, src.hparams()); src.optimizer_step(1e-3, 0.5, 1)
+    dst.copy_params_from(src)
+    want = src.get_params()
+    assert np.array_equal(dst.get_params(), want) and np.abs(want - flat).max() > 1e-5
+    a, b = src.forward(frames), dst.forward(frames)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and not np.array_equal(b[0], before)
+    st = dst.pinned((E // 2, 64, 64, 3), np.uint8); st[...] = frames[:E // 2]
+    dst.rollout_submit(0, 0, st, seed=3); got = dst.rollout_wait(0)
+    ref = src.rollout_step(0, seed=3)
+    assert np.array_equal(got[2], ref[2][:E // 2])
+    src.close(); dst.close()
+
+
 def test_philox_known_answers_and_the_samplers_uniforms():
     """The generator every real rollout samples with (csrc/misc.hip philox4x32_10 / philox_uniform) against (a) the Random123
     known-answer vectors for philox4x32 with 10 rounds (counter 0 / key 0, all ones, the pi digits), (b) the numpy restatement

@@ -356,7 +356,7 @@ class PPO(BaseAgent):
             obs, hidden_state, done = self._collect(self.env, self.engine, self.storage, obs, hidden_state, done)
             self.storage.compute_estimates(self.gamma, self.lmbda, self.use_gae, self.normalize_adv, self.coll)
             if self.env_valid is not None:
-                self.engine_valid.set_params(self.engine.get_params())
+                self.engine_valid.copy_params_from(self.engine)          # device to device (mi_copy_params)
                 obs_v, hidden_state_v, done_v = self._collect(self.env_valid, self.engine_valid, self.storage_valid,
                                                               obs_v, hidden_state_v, done_v)
                 self.storage_valid.compute_estimates(self.gamma, self.lmbda, self.use_gae, self.normalize_adv)

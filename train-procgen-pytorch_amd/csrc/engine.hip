@@ -509,6 +509,23 @@ int mi_sync(mi_ctx* c) { ARG(c, "ctx"); JOIN(c); HIPC(hipStreamSynchronize(c->st
 int64_t mi_param_count(mi_ctx* c) { return c ? c->n_params : -1; }
 int mi_set_params(mi_ctx* c, const float* flat, int64_t n) { ARG(c && flat, "null"); c->fc_packed_valid = false; return upload_flat(c, c->params, flat, n); }
 int mi_get_params(mi_ctx* c, float* flat, int64_t n) { ARG(c && flat, "null"); return download_flat(c, c->params, flat, n); }
+// PPO.train hands the freshly updated policy to the validation rollouts (agents/ppo.py:241-252 run them with the SAME policy object):
+// here the inference-only twin context takes the parameters device to device, in stream order on both sides (no host round trip).
+int mi_copy_params(mi_ctx* dst, mi_ctx* src) {
+    ARG(dst && src && dst != src, "null / same context"); JOIN(src); JOIN(dst);
+    ARG(dst->cfg.arch == src->cfg.arch && dst->n_params == src->n_params && dst->A == src->A && dst->H == src->H && dst->cfg.device == src->cfg.device,
+        "contexts of different architecture / size / device");
+    hipEvent_t ready = nullptr, done = nullptr;
+    HIPC(hipEventCreateWithFlags(&ready, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    HIPC(hipEventRecord(ready, src->stream));                      // the optimizer step that wrote src's parameters
+    HIPC(hipStreamWaitEvent(dst->stream, ready, 0));
+    HIPC(hipMemcpyAsync(dst->params, src->params, (size_t)src->n_params * 4, hipMemcpyDeviceToDevice, dst->stream));
+    HIPC(hipEventRecord(done, dst->stream));
+    HIPC(hipStreamWaitEvent(src->stream, done, 0));                // src's next optimizer step must not overtake the copy
+    dst->fc_packed_valid = false;                                  // packed bf16 filter images are rebuilt before dst's next pass
+    HIPC(hipEventDestroy(ready)); HIPC(hipEventDestroy(done));     // (released by the runtime once they have completed)
+    return 0;
+}
 int mi_get_grads(mi_ctx* c, float* flat, int64_t n) { ARG(c && flat, "null"); return download_flat(c, c->grads, flat, n); }
 int mi_set_adam_state(mi_ctx* c, const float* m, const float* v, int64_t n) {
     ARG(c && m && v, "null");

@@ -38,7 +38,7 @@ def lib_path():
 
 
 EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_free mi_host_register mi_host_unregister mi_param_count mi_set_params "
-           "mi_get_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
+           "mi_get_params mi_copy_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
            "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_rollout_groups mi_rollout_submit mi_rollout_wait mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_minibatch_multi mi_optimizer_step mi_loss_log_read mi_device_ptr "
            "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma mi_debug_read mi_debug_flags mi_comm_unique_id mi_comm_init mi_comm_destroy mi_allreduce_arm mi_allreduce_grads mi_allreduce_buffer mi_adv_normalize_global mi_minibatch_positions mi_debug_philox").split()
@@ -171,6 +171,10 @@ class Engine:
         out = np.empty(self.n_params, np.float32)
         self._chk(self.lib.mi_get_params(self._ctx, _fp(out), C.c_int64(out.size)))
         return out
+
+    def copy_params_from(self, src):
+        """This context's parameters := src's (another Engine on the same GPU), device to device, ordered on both streams."""
+        self._chk(self.lib.mi_copy_params(self._ctx, src._ctx))
 
     def get_grads(self):
         out = np.empty(self.n_params, np.float32)
