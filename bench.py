@@ -100,6 +100,46 @@ def cpu_baseline(hp, E, A, t_sample, threads):
                        f"(forward, backward, clip, Adam) {t_epoch:.1f} s, counted {hp['epoch']}x")
 
 
+def fp32_record(hp, T, E, A, G, device, rank, iters=3):
+    """The same iteration in the fp32 PARITY mode (the mode the 1e-4 loss / return parity with the reference is stated and tested in;
+    exact-fp32 matrix instructions), `iters` timed iterations after one warm-up, product collector included: a driver-run number for it
+    beside the bf16 headline."""
+    from agents.ppo import PPO
+    from common.env.vec_envs import EnvGroups, SyntheticTape
+    from common.model import ImpalaModel
+    from common.policy import CategoricalPolicy
+    from common.storage import Storage
+    torch.manual_seed(6033)
+    model = ImpalaModel(in_channels=3)
+    policy = CategoricalPolicy(model, False, A)
+    policy.device = device
+    storage = Storage((3, 64, 64), model.output_dim, T, E, device)
+
+    class _Log:
+        episode_reward_buffer = [0.0]
+        logdir = "/tmp"
+    agent = PPO(None, policy, _Log(), storage, device, 1, seed=rank, precision="fp32", **hp)
+    ng = E // G
+    env = EnvGroups([SyntheticTape(ng, A, seed=1000 * rank + g, length=T) for g in range(G)]) if G > 1 else SyntheticTape(E, A, seed=1000 * rank, length=T)
+    roll = [env.reset(), np.zeros((E, storage.hidden_state_size), np.float32), np.zeros(E, np.float32)]
+    t_roll = 0.0
+    for it in range(iters + 1):
+        if it == 1:
+            agent.engine.sync(); t_roll = 0.0; t0 = time.perf_counter()
+        agent._iter = it + 1
+        tr = time.perf_counter()
+        roll = list(agent._collect(env, agent.engine, storage, *roll))
+        t_roll += time.perf_counter() - tr
+        storage.compute_estimates(hp["gamma"], hp["lmbda"], hp["use_gae"], hp["normalize_adv"], agent.coll)
+        summary = agent.optimize()
+    agent.engine.sync()
+    dt = time.perf_counter() - t0
+    agent.engine.close()
+    return {"value": T * E * iters / dt, "unit": "env steps/s", "ms_per_step": dt / iters * 1e3, "steps": iters, "rollout_ms": t_roll / iters * 1e3,
+            "dtype": "f32", "loss_total": summary["Loss/total"],
+            "whole_step_roofline_mfma_frac": T * E * iters / dt * 601.78e6 / (MFMA_F32_PEAK_TF * 1e12)}
+
+
 def rocprof_name(cls, precision):
     """kernel class of the live profiler -> substrings that identify its rocprofv3 kernel name (template arguments)."""
     parts = cls.split("_")
@@ -214,6 +254,7 @@ def main():
                     "the default uploads every step's E frames from pinned host memory inside the timed region, as the real loop must")
     ap.add_argument("--engine-only", action="store_true", help="diagnostic: the rollout phase drives mi_rollout_submit / mi_rollout_wait directly with frames "
                     "that already lie in pinned buffers (rounds 1-2's loop) instead of the product's collector PPO._collect on an EnvGroups env")
+    ap.add_argument("--no-fp32-record", action="store_true", help="skip the three extra iterations in the fp32 parity mode (the `fp32` sub-record)")
     ap.add_argument("--n-actions", type=int, default=9, help="action count A: 9 = the reference's default for Procgen (ActionWrapper merges the 15 key "
                     "combinations by name, helper_local.py:653), 15 = --no-reduce_duplicate_actions")
     ap.add_argument("--rollout-groups", type=int, default=0, help="env groups of the pipelined rollout (0 = auto: 4 when n_envs >= 128 divides, else 2; "
@@ -416,6 +457,9 @@ def main():
                "kernel_profile_period": (0 if args.no_kernel_profile else max(1, args.profile_period)),    # kernels[]: the bracketed sample only
                "kernels": sorted(prof, key=lambda r: -r["ms"])[:24],
                "loss_total": summary["Loss/total"]}
+        if world == 1 and args.precision == "bf16" and not args.no_fp32_record and not args.engine_only and args.rank_share == 1:
+            eng.close()
+            out["fp32"] = fp32_record(hp, T, E, A, G, device, rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hp, E, A, args.cpu_sample, args.cpu_threads or host_cores())
         print(json.dumps(out))

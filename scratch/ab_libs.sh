@@ -6,7 +6,7 @@ L=train-procgen-pytorch_amd/mi355/libmi355ppo.so
 cp $L /tmp/lib_orig.so
 for r in $(seq $R); do for v in $A $B; do
   cp $v $L
-  python bench.py --steps 6 --warmup 2 --no-cpu-baseline --profile-period 2 > /tmp/ab.json 2>/tmp/ab.err || { tail -5 /tmp/ab.err; cp /tmp/lib_orig.so $L; exit 1; }
+  python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-record --profile-period 2 > /tmp/ab.json 2>/tmp/ab.err || { tail -5 /tmp/ab.err; cp /tmp/lib_orig.so $L; exit 1; }
   python - "$v" "$K" <<'PY'
 import json,sys
 d=json.loads(open('/tmp/ab.json').read().strip().splitlines()[-1])

@@ -488,9 +488,15 @@ struct RbFullArgs {
     int n;
 };
 
-#ifndef RBFULL_CFG
-#define RBFULL_CFG 8, 256          // tile rows, threads per workgroup (16 rows x 512 threads, 92 KB, one workgroup per CU: 14.8 vs 13.8 ms)
+#ifndef RBFULL_WG_REUSE
+#define RBFULL_WG_REUSE 1          // weight-gradient operand rows shared between a wave's two consecutive pixel rows (see the kernel)
 #endif
+#ifndef RBFULL_CFG
+#define RBFULL_CFG 8, 256          // tile rows, threads per workgroup: every wave holds both layers' 20 weight-gradient tiles, 250 registers, 2 waves per SIMD.
+#endif                             // Measured alternatives (scratch/kbench_rb16.hip, us per 8192-sample launch on random data, this config 349-365):
+                                   //  8 x 512 = two workgroups of 8 waves per CU = 4 waves per SIMD at <= 128 registers, weight-gradient accumulators split by
+                                   //  LAYER over the wave halves (waves 0-3 conv2's, 4-7 conv1's), four staging words per thread in one index space: needs 160
+                                   //  registers, so 19 spill at 128 -- 378-384; 16 x 512, 92 KB, one workgroup per CU: 14.8 vs 13.8 ms per iteration (round 1)
 template <int TH_, int NT_>
 struct RbFullT {                                 // C = 16, HW = 32
     static constexpr int C = 16, HW = 32, TH = TH_, NT = NT_, NW = NT_ / 64, S = 16, P = HW + 2, TPI = HW / TH;
@@ -508,7 +514,13 @@ struct RbFullT {                                 // C = 16, HW = 32
 };
 using RbFull = RbFullT<RBFULL_CFG>;
 
-__global__ __launch_bounds__(RbFull::NT, 2) void resblock_bwd_full_bf16_kernel(RbFullArgs a) {      // 2 waves per SIMD: <= 256 registers
+#ifdef RBF_TIMING      // scratch/kbench_rb16.hip: per-phase shader-clock totals of wave 0, summed over workgroups
+__device__ unsigned long long g_rbf_timing[8];
+#define RBF_TCK(k) do { if (tid == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
+#else
+#define RBF_TCK(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(RbFull::NT, RbFull::NT == 512 ? 4 : 2) void resblock_bwd_full_bf16_kernel(RbFullArgs a) {      // 512 threads: 4 waves per SIMD, <= 128 registers
     using C = RbFull;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_x = smem_h;                         // dy rows ty0-2 .. ty0+TH+1
@@ -526,53 +538,101 @@ __global__ __launch_bounds__(RbFull::NT, 2) void resblock_bwd_full_bf16_kernel(R
         int tap = 2 * m + (kq >> 1); const int chunk = kq & 1; if (tap > 8) tap = 8;
         koff[m] = ((tap / 3) * C::P + (tap % 3)) * C::S + chunk * 8;
     }
-    f32x4 acc2[9], acc1[9], accb2 = {0.f, 0.f, 0.f, 0.f}, accb1 = {0.f, 0.f, 0.f, 0.f};     // weight-gradient tiles of conv2 / conv1, bias rows
+    constexpr bool SPLIT = C::NW == 8;               // weight gradients: waves 0-3 own conv2's tiles (acc2), waves 4-7 conv1's (held in acc2 as well)
+    constexpr int NACC1 = 9;                         // (SPLIT: acc1 / accb1 are never used and vanish)
+    f32x4 acc2[9], acc1[NACC1], accb2 = {0.f, 0.f, 0.f, 0.f}, accb1 = {0.f, 0.f, 0.f, 0.f};     // weight-gradient tiles of conv2 / conv1, bias rows
 #pragma unroll
-    for (int t = 0; t < 9; ++t) { acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < 9; ++t) acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NACC1; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
     const int nwork = a.n * C::TPI;
-    uint4 rx[C::KX], ra[C::KA], rp[C::KA];
+#ifdef RBF_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
+#endif
+    // 512 threads: the three tiles of an item are 768 + 640 + 640 = 2048 16-byte words = exactly four per thread in ONE index space (a
+    // thread's word k is e = tid + 512 k: dy for e < 768, then relu(a), then relu(x)): 16 staging registers instead of 24 with a per-tensor
+    // split that leaves the second word of every tensor half empty -- the kernel has 128 registers per thread.
+    constexpr bool UNI = C::NT == 512;
+    static_assert(!UNI || C::NX + 2 * C::NA == 4 * C::NT, "unified staging: four words per thread");
+    uint4 ru[UNI ? 4 : 1];
+    auto uni_word = [&](int e, int& t, int& le) { t = e < C::NX ? 0 : (e < C::NX + C::NA ? 1 : 2); le = e - (t == 0 ? 0 : (t == 1 ? C::NX : C::NX + C::NA)); };
+    uint4 rx[UNI ? 1 : C::KX], ra[UNI ? 1 : C::KA], rp[UNI ? 1 : C::KA];
+    // Next item's tiles into registers while this one is computed.  Every load is UNCONDITIONAL from a row clamped into the image and a
+    // word index clamped into the tile (rows outside the image / threads past the tile are replaced by zeros when the registers are
+    // stored): `v = 0; if (row in image) v = load` merges the loaded registers with older values and the compiler then waits for the
+    // loads right where they are issued -- the item paid a full HBM round trip there (1180 of 9200 cycles per item, scratch/kbench_rb16.hip).
     auto load = [&](int work) {
         const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+        if constexpr (UNI) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int t, le; uni_word(tid + k * C::NT, t, le);
+                const int c8 = le & 1, px = (le >> 1) % C::HW; int gy = ty0 - (t == 0 ? 2 : 1) + le / (2 * C::HW);
+                gy = gy < 0 ? 0 : (gy > C::HW - 1 ? C::HW - 1 : gy);
+                const unsigned short* src = t == 0 ? a.dy : (t == 1 ? a.a_fwd : a.x_fwd);
+                ru[k] = *(const uint4*)(src + ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < C::KX; ++k) {
-            const int e = tid + k * C::NT;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (e < C::NX) { const int c8 = e & 1, px = (e >> 1) % C::HW, gy = ty0 - 2 + e / (2 * C::HW);
-                             if (gy >= 0 && gy < C::HW) v = *(const uint4*)(a.dy + ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8); }
-            rx[k] = v;
+            int e = tid + k * C::NT; e = e < C::NX ? e : C::NX - 1;
+            const int c8 = e & 1, px = (e >> 1) % C::HW; int gy = ty0 - 2 + e / (2 * C::HW);
+            gy = gy < 0 ? 0 : (gy > C::HW - 1 ? C::HW - 1 : gy);
+            rx[k] = *(const uint4*)(a.dy + ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8);
         }
 #pragma unroll
         for (int k = 0; k < C::KA; ++k) {
-            const int e = tid + k * C::NT;
-            uint4 va = {0u, 0u, 0u, 0u}, vp = {0u, 0u, 0u, 0u};
-            if (e < C::NA) { const int c8 = e & 1, px = (e >> 1) % C::HW, gy = ty0 - 1 + e / (2 * C::HW);
-                             if (gy >= 0 && gy < C::HW) { const long long o = ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8;
-                                                          va = *(const uint4*)(a.a_fwd + o); vp = *(const uint4*)(a.x_fwd + o); } }
-            ra[k] = va; rp[k] = vp;
+            int e = tid + k * C::NT; e = e < C::NA ? e : C::NA - 1;
+            const int c8 = e & 1, px = (e >> 1) % C::HW; int gy = ty0 - 1 + e / (2 * C::HW);
+            gy = gy < 0 ? 0 : (gy > C::HW - 1 ? C::HW - 1 : gy);
+            const long long o = ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8;
+            ra[k] = *(const uint4*)(a.a_fwd + o); rp[k] = *(const uint4*)(a.x_fwd + o);
         }
     };
+    auto item = [&](int w) { return w < nwork ? w : nwork - 1; };            // past the end: the last item again (loads stay unconditional)
     if ((int)blockIdx.x < nwork) load(blockIdx.x);
     for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
         const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+        RBF_TCK(0);
         __syncthreads();
+        RBF_TCK(1);
+        if constexpr (UNI) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int t, le; uni_word(tid + k * C::NT, t, le);
+                const int ry = le / (2 * C::HW), gy = ty0 - (t == 0 ? 2 : 1) + ry;
+                const bool in = gy >= 0 && gy < C::HW;
+                unsigned short* dst = (t == 0 ? s_x : (t == 1 ? s_a : s_p)) + (ry * C::P + (le >> 1) % C::HW + 1) * C::S + (le & 1) * 8;
+                const uint4 v = ru[k];
+                const uint4 r = t == 0 ? v : (uint4){rb_relu2(v.x), rb_relu2(v.y), rb_relu2(v.z), rb_relu2(v.w)};
+                *(uint4*)dst = in ? r : (uint4){0u, 0u, 0u, 0u};
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < C::KX; ++k) {
-            const int e = tid + k * C::NT;
-            if (e < C::NX) *(uint4*)(s_x + ((e / (2 * C::HW)) * C::P + (e >> 1) % C::HW + 1) * C::S + (e & 1) * 8) = rx[k];
+            const int e = tid + k * C::NT, gy = ty0 - 2 + e / (2 * C::HW);
+            const bool in = gy >= 0 && gy < C::HW;
+            if (e < C::NX) *(uint4*)(s_x + ((e / (2 * C::HW)) * C::P + (e >> 1) % C::HW + 1) * C::S + (e & 1) * 8) = in ? rx[k] : (uint4){0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int k = 0; k < C::KA; ++k) {
-            const int e = tid + k * C::NT;
+            const int e = tid + k * C::NT, gy = ty0 - 1 + e / (2 * C::HW);
+            const bool in = gy >= 0 && gy < C::HW;
             if (e < C::NA) {
                 const int o = ((e / (2 * C::HW)) * C::P + (e >> 1) % C::HW + 1) * C::S + (e & 1) * 8;
-                *(uint4*)(s_a + o) = (uint4){rb_relu2(ra[k].x), rb_relu2(ra[k].y), rb_relu2(ra[k].z), rb_relu2(ra[k].w)};
-                *(uint4*)(s_p + o) = (uint4){rb_relu2(rp[k].x), rb_relu2(rp[k].y), rb_relu2(rp[k].z), rb_relu2(rp[k].w)};
+                *(uint4*)(s_a + o) = in ? (uint4){rb_relu2(ra[k].x), rb_relu2(ra[k].y), rb_relu2(ra[k].z), rb_relu2(ra[k].w)} : (uint4){0u, 0u, 0u, 0u};
+                *(uint4*)(s_p + o) = in ? (uint4){rb_relu2(rp[k].x), rb_relu2(rp[k].y), rb_relu2(rp[k].z), rb_relu2(rp[k].w)} : (uint4){0u, 0u, 0u, 0u};
             }
         }
+        }
+        RBF_TCK(2);
         __syncthreads();
-        if (work + (int)gridDim.x < nwork) load(work + gridDim.x);
+        RBF_TCK(3);
+        load(item(work + gridDim.x));
+        RBF_TCK(4);
 
         // ---- da = convT2(dy) * (a > 0) on rows ty0-1 .. ty0+TH -> s_y (rows outside the image: relu(a) is 0 there, so da is 0)
         {
@@ -594,6 +654,7 @@ __global__ __launch_bounds__(RbFull::NT, 2) void resblock_bwd_full_bf16_kernel(R
                     const bf16x8 bv = *(const bf16x8*)(s_w1 + bbase + m * 32);
 #pragma unroll
                     for (int mt = 0; mt < C::MT1; ++mt) acc[mt][0] = MFMA_BF16(bv, *(const bf16x8*)(s_x + abase[mt] + koff[m]), acc[mt][0]);
+                    if constexpr (SPLIT) __builtin_amdgcn_sched_barrier(0);      // (128 registers: no operand reads hoisted across K steps; 4 waves per SIMD cover the LDS latency)
                 }
             }
 #pragma unroll
@@ -611,7 +672,9 @@ __global__ __launch_bounds__(RbFull::NT, 2) void resblock_bwd_full_bf16_kernel(R
                 }
             }
         }
+        RBF_TCK(5);
         __syncthreads();
+        RBF_TCK(6);
         // ---- dx = convT1(da) * (x > 0) + dy on rows ty0 .. ty0+TH-1 -> HBM
         {
             int abase[C::MT2];
@@ -626,6 +689,7 @@ __global__ __launch_bounds__(RbFull::NT, 2) void resblock_bwd_full_bf16_kernel(R
                 const bf16x8 bv = *(const bf16x8*)(s_w2 + bbase + m * 32);
 #pragma unroll
                 for (int mt = 0; mt < C::MT2; ++mt) acc[mt] = MFMA_BF16(bv, *(const bf16x8*)(s_y + abase[mt] + koff[m]), acc[mt]);
+                if constexpr (SPLIT) __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int mt = 0; mt < C::MT2; ++mt) {
@@ -638,7 +702,81 @@ __global__ __launch_bounds__(RbFull::NT, 2) void resblock_bwd_full_bf16_kernel(R
                 *(uint2*)(a.dx_out + ((img * C::HW + ty0 + oy) * C::HW + px) * C::C + kq * 4) = rb_pack(v);
             }
         }
+        RBF_TCK(7);
         // ---- weight gradients: conv2 from (dy, relu(a)), conv1 from (da, relu(x)); pixel steps of 32 dealt to the waves
+#if RBFULL_WG_REUSE
+        // A pixel step is one image row (HW = 32), and the tap (ky, kx) operand of row r is row r + ky of the staged relu(a) / relu(x)
+        // tile shifted by kx: a wave that owns CONSECUTIVE rows r0, r0 + 1 needs tile rows r0 .. r0 + 3 only once each -- 12 operand
+        // fragments per layer for its 18 (row, tap) products instead of 18 (56 transposing LDS reads per wave and item instead of 80;
+        // the kernel is LDS-pipe / latency bound).  Every accumulator still receives its rows in ascending order.
+        static_assert(C::HW == 32 && (C::NSTEP == 2 * C::NW || (SPLIT && C::NSTEP == C::NW)), "one row per pixel step, two consecutive rows per wave (pair)");
+        if constexpr (SPLIT) {
+            // one code path for both halves (two paths made the compiler keep two accumulator sets): role 0 = conv2 from (dy, relu(a)),
+            // role 1 = conv1 from (da, relu(x)); the operand tiles differ by base pointer and by the row offset of the gradient tile
+            const int role = wave >> 2, r0 = 2 * (wave & 3);
+            const unsigned short* s_d = role ? s_y : s_x;
+            const unsigned short* s_b = role ? s_p : s_a;
+            const int drow = role ? 1 : 2;
+            int ocol[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) ocol[h] = (16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq) * C::S + 4 * cp;
+            auto tr = [&](const unsigned short* base, int off) {
+                const rb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + ocol[0] + off));
+                const rb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + ocol[1] + off));
+                return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            bf16x8 dd[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dd[j] = tr(s_d, ((r0 + j + drow) * C::P + 1) * C::S);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accb2 = MFMA_BF16(dd[j], ones, accb2);
+#pragma unroll
+            for (int R = 0; R < 4; ++R)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bf16x8 fb = tr(s_b, ((r0 + R) * C::P + kx) * C::S);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ky = R - j;
+                        if (ky < 0 || ky > 2) continue;
+                        acc2[ky * 3 + kx] = MFMA_BF16(dd[j], fb, acc2[ky * 3 + kx]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);            // (128 registers: at most one operand fragment ahead of its products)
+                }
+        } else {
+            const int r0 = 2 * wave;
+            int ocol[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) ocol[h] = (16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq) * C::S + 4 * cp;
+            auto tr = [&](const unsigned short* base, int off) {
+                const rb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + ocol[0] + off));
+                const rb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + ocol[1] + off));
+                return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            bf16x8 d2[2], d1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                d2[j] = tr(s_x, ((r0 + j + 2) * C::P + 1) * C::S);      // dy at the pixel   (s_x row 0 = ty0-2, col 0 = -1)
+                d1[j] = tr(s_y, ((r0 + j + 1) * C::P + 1) * C::S);      // da at the pixel   (s_y row 0 = ty0-1)
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { accb2 = MFMA_BF16(d2[j], ones, accb2); accb1 = MFMA_BF16(d1[j], ones, accb1); }
+#pragma unroll
+            for (int R = 0; R < 4; ++R)                                  // tile row r0 + R of s_a / s_p (row 0 = ty0-1, col 0 = -1)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int off = ((r0 + R) * C::P + kx) * C::S;
+                    const bf16x8 fa = tr(s_a, off), fp = tr(s_p, off);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ky = R - j;
+                        if (ky < 0 || ky > 2) continue;
+                        acc2[ky * 3 + kx] = MFMA_BF16(d2[j], fa, acc2[ky * 3 + kx]);
+                        acc1[ky * 3 + kx] = MFMA_BF16(d1[j], fp, acc1[ky * 3 + kx]);
+                    }
+                }
+        }
+#else
         for (int t = wave; t < C::NSTEP; t += C::NW) {
             int orow[2];                                   // this lane's two source pixels (interior coordinates), MFMA k permutation as in conv_bf16.hip
 #pragma unroll
@@ -662,11 +800,44 @@ __global__ __launch_bounds__(RbFull::NT, 2) void resblock_bwd_full_bf16_kernel(R
                 acc1[tap] = MFMA_BF16(d1, tr(s_p, toff), acc1[tap]);
             }
         }
+#endif
     }
+#ifdef RBF_TIMING
+    if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_rbf_timing[k], (unsigned long long)tacc_[k]);
+#endif
     // ---- waves summed through LDS in fixed order; one slab per workgroup and layer
     __syncthreads();
     float* red = (float*)smem_h;                              // [2][WLEN] then [2][NW][16] bias partials
     float* redb = red + 2 * C::WLEN;
+    if constexpr (SPLIT) {
+        // waves 0-3 hold conv2's tiles, waves 4-7 conv1's (both in acc2 / accb2): the two halves sum side by side, each in wave order
+        const int role = wave >> 2, wl = wave & 3;
+        for (int w = 0; w < 4; ++w) {
+            if (wl == w) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = role * C::WLEN + ((kq * 4 + r) * 9 + tap) * C::C + i;
+                        red[o] = (w == 0) ? acc2[tap][r] : red[o] + acc2[tap][r];
+                    }
+            }
+            __syncthreads();
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) redb[(role * 4 + wl) * 16 + kq * 4 + r] = accb2[r];
+        }
+        __syncthreads();
+        float* sl2 = a.slab2 + (long long)blockIdx.x * C::SLAB;
+        float* sl1 = a.slab1 + (long long)blockIdx.x * C::SLAB;
+        for (int e = tid; e < C::WLEN; e += C::NT) { sl2[e] = red[e]; sl1[e] = red[C::WLEN + e]; }
+        if (tid < 16) {
+            float t2 = 0.f, t1 = 0.f;
+            for (int w = 0; w < 4; ++w) { t2 += redb[w * 16 + tid]; t1 += redb[(4 + w) * 16 + tid]; }
+            sl2[C::WLEN + tid] = t2; sl1[C::WLEN + tid] = t1;
+        }
+    } else {
     for (int w = 0; w < C::NW; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -692,6 +863,7 @@ __global__ __launch_bounds__(RbFull::NT, 2) void resblock_bwd_full_bf16_kernel(R
         float t2 = 0.f, t1 = 0.f;
         for (int w = 0; w < C::NW; ++w) { t2 += redb[w * 16 + tid]; t1 += redb[C::NW * 16 + w * 16 + tid]; }
         sl2[C::WLEN + tid] = t2; sl1[C::WLEN + tid] = t1;
+    }
     }
 }
 int resblock_bwd_full_grid(int n) {
