@@ -242,6 +242,9 @@ int mi_debug_read(mi_ctx* ctx, int32_t which, int32_t n, float* out);
  * n x {c0,c1,c2,c3,k0,k1} in; out4 = n x 4 output words of the ten-round bijection (checked against the Random123 known-answer
  * vectors), u_out = n uniforms exactly as the sample kernels draw them for seed = k0 | k1 << 32, counter = c0 | c1 << 32. */
 int mi_debug_philox(mi_ctx* ctx, const uint32_t* ctr_key6, int32_t n, uint32_t* out4, float* u_out);
+/* measurement hook: wall-clock microseconds per policy step of slot t (the step's launches + a stream wait, `iters` times), issued
+ * eagerly (mode 0) or as one replay of a hipGraph captured from the same launches (mode 1) */
+int mi_debug_step_latency(mi_ctx* ctx, int32_t t, int32_t iters, int32_t mode, float* us_out);
 /* bit 0 set: rollout-sized bf16 inference passes use the separate block-2 / block-3 kernels instead of the fused launch
  * (rollout_bf16.hip) -- the A side of the bit-equality test of the two paths;
  * bit 2 set: a group's frames always go up by DMA copy, never pulled by a kernel (A/B timing) */

@@ -1949,6 +1949,46 @@ int mi_debug_philox(mi_ctx* c, const uint32_t* ctr_key6, int32_t n, uint32_t* ou
     return 0;
 }
 
+// Measurement hook ("hipGraph"): wall-clock microseconds per policy step of slot t -- the step's launches (conv stack,
+// embedder.fc, fused heads + sample: 5 kernels in bf16 mode) followed by a stream wait, `iters` times back to back -- issued eagerly
+// (mode 0) or as ONE replay of a graph captured from the same launches (mode 1).  What a captured group step could save on the
+// rollout's dependency chain, without touching the production path (whose per-step arguments change: slot, counters, ticket).
+int mi_debug_step_latency(mi_ctx* c, int32_t t, int32_t iters, int32_t mode, float* us_out) {
+    ARG(c && us_out, "null"); JOIN(c); ARG(t >= 0 && t <= c->T && iters >= 1 && (mode == 0 || mode == 1), "t / iters / mode");
+    const int E = c->E;
+    InputSrc src{c->frames ? (const void*)c->frames : (const void*)c->obsf, nullptr, (long long)t * E};
+    auto issue = [&]() {
+        c->prof.phase = 0;
+        net_forward(c, src, E, true, false);
+        launch_heads_sample(c->feat, c->params + c->wh_off, c->params + c->bh_off, E, c->H, c->A, nullptr, 1234ull, (unsigned long long)t * E,
+                            nullptr, nullptr, c->value + (size_t)t * E, c->h_pack, nullptr, nullptr, nullptr, nullptr, c->stream);
+    };
+    const bool prof_on = c->prof.on; c->prof.on = false;       // (no event records inside a capture)
+    issue();                                                   // warm: packed banks in place, lazy function attributes set
+    HIPC(hipGetLastError()); NETCHK(c);
+    HIPC(hipStreamSynchronize(c->stream));
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    if (mode == 1) {
+        HIPC(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        issue();
+        HIPC(hipStreamEndCapture(c->stream, &graph));
+        HIPC(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIPC(hipGraphLaunch(exec, c->stream)); HIPC(hipStreamSynchronize(c->stream));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < iters; ++k) {
+        if (mode == 1) HIPC(hipGraphLaunch(exec, c->stream)); else issue();
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    *us_out = (float)(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() / 1e3 / iters);
+    if (exec) hipGraphExecDestroy(exec);
+    if (graph) hipGraphDestroy(graph);
+    c->prof.on = prof_on;
+    HIPC(hipGetLastError()); NETCHK(c);
+    return 0;
+}
+
 // Read back what the last training-mode pass (mi_minibatch) left in the activation buffers, as fp32 NHWC: which = 8 * block + k with
 // k = 0 P0 (pooled map), 1 A1, 2 P1, 3 A2, 4 P2 (res1.conv1 out, res1 out, res2.conv1 out, block out), 5 the max-pool arg-max bytes
 // (window position ky*3+kx as float); which = 100: the 256 features.  For teacher-forced backward parity tests.

@@ -491,6 +491,9 @@ struct RbFullArgs {
 #ifndef RBFULL_WG_REUSE
 #define RBFULL_WG_REUSE 1          // weight-gradient operand rows shared between a wave's two consecutive pixel rows (see the kernel)
 #endif
+#ifndef RBFULL_SPREAD_LOADS
+#define RBFULL_SPREAD_LOADS 1
+#endif
 #ifndef RBFULL_CFG
 #define RBFULL_CFG 8, 256          // tile rows, threads per workgroup: every wave holds both layers' 20 weight-gradient tiles, 250 registers, 2 waves per SIMD.
 #endif                             // Measured alternatives (scratch/kbench_rb16.hip, us per 8192-sample launch on random data, this config 349-365):
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(RbFull::NT, RbFull::NT == 512 ? 4 : 2) void resbloc
     // word index clamped into the tile (rows outside the image / threads past the tile are replaced by zeros when the registers are
     // stored): `v = 0; if (row in image) v = load` merges the loaded registers with older values and the compiler then waits for the
     // loads right where they are issued -- the item paid a full HBM round trip there (1180 of 9200 cycles per item, scratch/kbench_rb16.hip).
-    auto load = [&](int work) {
+    auto load = [&](int work, int part = 7) {            // part bits: 1 = dy words, 2 = relu(a) words, 4 = relu(x) words
         const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
         if constexpr (UNI) {
 #pragma unroll
@@ -576,6 +579,7 @@ __global__ __launch_bounds__(RbFull::NT, RbFull::NT == 512 ? 4 : 2) void resbloc
             }
             return;
         }
+        if (part & 1) {
 #pragma unroll
         for (int k = 0; k < C::KX; ++k) {
             int e = tid + k * C::NT; e = e < C::NX ? e : C::NX - 1;
@@ -583,13 +587,15 @@ __global__ __launch_bounds__(RbFull::NT, RbFull::NT == 512 ? 4 : 2) void resbloc
             gy = gy < 0 ? 0 : (gy > C::HW - 1 ? C::HW - 1 : gy);
             rx[k] = *(const uint4*)(a.dy + ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8);
         }
+        }
 #pragma unroll
         for (int k = 0; k < C::KA; ++k) {
             int e = tid + k * C::NT; e = e < C::NA ? e : C::NA - 1;
             const int c8 = e & 1, px = (e >> 1) % C::HW; int gy = ty0 - 1 + e / (2 * C::HW);
             gy = gy < 0 ? 0 : (gy > C::HW - 1 ? C::HW - 1 : gy);
             const long long o = ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8;
-            ra[k] = *(const uint4*)(a.a_fwd + o); rp[k] = *(const uint4*)(a.x_fwd + o);
+            if (part & 2) ra[k] = *(const uint4*)(a.a_fwd + o);
+            if (part & 4) rp[k] = *(const uint4*)(a.x_fwd + o);
         }
     };
     auto item = [&](int w) { return w < nwork ? w : nwork - 1; };            // past the end: the last item again (loads stay unconditional)
@@ -631,7 +637,14 @@ __global__ __launch_bounds__(RbFull::NT, RbFull::NT == 512 ? 4 : 2) void resbloc
         RBF_TCK(2);
         __syncthreads();
         RBF_TCK(3);
+#if RBFULL_SPREAD_LOADS
+        // the next item's 9 loads per thread are ISSUED in three pieces, in front of each compute phase: in one piece their issue alone took
+        // ~1000 of an item's ~9200 cycles per workgroup (36 KB through a 64 B/clk path shared with the CU's other workgroup) with nothing else running
+        const int wnext = item(work + gridDim.x);
+        load(wnext, 1);
+#else
         load(item(work + gridDim.x));
+#endif
         RBF_TCK(4);
 
         // ---- da = convT2(dy) * (a > 0) on rows ty0-1 .. ty0+TH -> s_y (rows outside the image: relu(a) is 0 there, so da is 0)
@@ -654,6 +667,9 @@ __global__ __launch_bounds__(RbFull::NT, RbFull::NT == 512 ? 4 : 2) void resbloc
                     const bf16x8 bv = *(const bf16x8*)(s_w1 + bbase + m * 32);
 #pragma unroll
                     for (int mt = 0; mt < C::MT1; ++mt) acc[mt][0] = MFMA_BF16(bv, *(const bf16x8*)(s_x + abase[mt] + koff[m]), acc[mt][0]);
+#if RBFULL_SPREAD_LOADS == 2
+                    if (m == 1) load(wnext, 2);
+#endif
                     if constexpr (SPLIT) __builtin_amdgcn_sched_barrier(0);      // (128 registers: no operand reads hoisted across K steps; 4 waves per SIMD cover the LDS latency)
                 }
             }
@@ -675,6 +691,11 @@ __global__ __launch_bounds__(RbFull::NT, RbFull::NT == 512 ? 4 : 2) void resbloc
         RBF_TCK(5);
         __syncthreads();
         RBF_TCK(6);
+#if RBFULL_SPREAD_LOADS == 2
+        load(wnext, 4);
+#elif RBFULL_SPREAD_LOADS
+        load(wnext, 2);
+#endif
         // ---- dx = convT1(da) * (x > 0) + dy on rows ty0 .. ty0+TH-1 -> HBM
         {
             int abase[C::MT2];
@@ -703,6 +724,9 @@ __global__ __launch_bounds__(RbFull::NT, RbFull::NT == 512 ? 4 : 2) void resbloc
             }
         }
         RBF_TCK(7);
+#if RBFULL_SPREAD_LOADS == 1
+        load(wnext, 4);
+#endif
         // ---- weight gradients: conv2 from (dy, relu(a)), conv1 from (da, relu(x)); pixel steps of 32 dealt to the waves
 #if RBFULL_WG_REUSE
         // A pixel step is one image row (HW = 32), and the tap (ky, kx) operand of row r is row r + ky of the staged relu(a) / relu(x)

@@ -41,7 +41,7 @@ EXPORTS = ("mi_last_error mi_create mi_destroy mi_sync mi_host_alloc mi_host_fre
            "mi_get_params mi_copy_params mi_get_grads mi_set_adam_state mi_get_adam_state mi_put_obs mi_get_obs mi_put_step "
            "mi_put_policy_outputs mi_read_field mi_write_field mi_policy_step mi_rollout_step mi_rollout_groups mi_rollout_submit mi_rollout_wait mi_predict_staged mi_value_saliency mi_commit_staged mi_set_gru mi_rec_state mi_get_hidden mi_forward_rec mi_forward mi_compute_estimates "
            "mi_adv_stats mi_adv_apply mi_minibatch mi_minibatch_multi mi_optimizer_step mi_loss_log_read mi_device_ptr "
-           "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma mi_debug_read mi_debug_flags mi_comm_unique_id mi_comm_init mi_comm_destroy mi_allreduce_arm mi_allreduce_grads mi_allreduce_buffer mi_adv_normalize_global mi_minibatch_positions mi_debug_philox").split()
+           "mi_set_multirank mi_minibatch_finish mi_loss_log_finalize mi_profile_enable mi_profile_read mi_profile_class_name mi_op_conv3x3 mi_op_resblock mi_op_maxpool mi_op_gemm mi_selftest_mfma mi_debug_read mi_debug_flags mi_comm_unique_id mi_comm_init mi_comm_destroy mi_allreduce_arm mi_allreduce_grads mi_allreduce_buffer mi_adv_normalize_global mi_minibatch_positions mi_debug_philox mi_debug_step_latency").split()
 
 
 def load_library():
@@ -517,6 +517,12 @@ class Engine:
         out, u = np.empty((a.shape[0], 4), np.uint32), np.empty(a.shape[0], np.float32)
         self._chk(self.lib.mi_debug_philox(self._ctx, _fp(a), C.c_int32(a.shape[0]), _fp(out), _fp(u)))
         return out, u
+
+    def debug_step_latency(self, t, iters=200, graph=False):
+        """microseconds per policy step of slot t (launches + stream wait), eager or as a replayed hipGraph of the same launches"""
+        us = C.c_float(0)
+        self._chk(self.lib.mi_debug_step_latency(self._ctx, C.c_int32(t), C.c_int32(iters), C.c_int32(int(graph)), C.byref(us)))
+        return us.value
 
     def debug_flags(self, flags):
         self._chk(self.lib.mi_debug_flags(self._ctx, C.c_int32(flags)))
