@@ -124,8 +124,10 @@ int mi_rollout_wait(mi_ctx* ctx, int32_t group, int64_t* act_out, float* logp_ou
 int mi_predict_staged(mi_ctx* ctx, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
                       int64_t* act_out, float* logp_out, float* value_out);
 /* PPO.predict_w_value_saliency (agents/ppo.py:83-94): mi_predict_staged + d value / d observation (value.backward()): grad_out is
- * [E][64][64][3] floats (NHWC, with respect to the k/255 float frames) for IMPALA, [E][obs_dim] for the MLP.  Not for recurrent
- * policies; discards (zeroes) the parameter-gradient buffer, so not inside an accumulating update. */
+ * [E][64][64][3] floats (NHWC, with respect to the k/255 float frames) for IMPALA, [E][obs_dim] for the MLP.  With a GRU set (mi_set_gru)
+ * the step is the recurrent one -- it consumes the hidden state / done flags of mi_rec_state and advances the state like a policy step --
+ * and the gradient runs back through the GRU cell's input path (common/model.py:219-225 under autograd).  Discards (zeroes) the
+ * parameter-gradient buffer, so not inside an accumulating update. */
 int mi_value_saliency(mi_ctx* ctx, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
                       int64_t* act_out, float* logp_out, float* value_out, float* grad_out);
 int mi_commit_staged(mi_ctx* ctx, int32_t t);

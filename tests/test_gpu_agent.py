@@ -232,6 +232,12 @@ def test_recurrent_policy_golden_and_agent_flow():
     assert all(torch.equal(a, b) for a, b in zip(gru_before, policy.gru.parameters()))
     sd = agent.optimizer.state_dict()
     assert len(sd["param_groups"][0]["params"]) == 40 and len(sd["state"]) == 36      # frozen GRU: no Adam state
+    # predict_w_value_saliency of the recurrent policy (agents/ppo.py:83-94): the policy step's numbers + d value / d obs through the GRU
+    h_in, d_in = hid.copy(), np.zeros(E, np.float32)
+    a_p, lp_p, v_p, h_p = agent.predict(obs, h_in, d_in)
+    a_s, lp_s, v_s, h_s, sal = agent.predict_w_value_saliency(obs, h_in, d_in)
+    np.testing.assert_allclose(v_s, v_p, atol=1e-6); np.testing.assert_allclose(h_s, h_p, atol=1e-6)
+    assert sal.shape == (E, 3, 64, 64) and np.isfinite(sal).all() and np.abs(sal).max() > 0 and np.abs(h_s - h_in).max() > 0
 
 
 def test_recurrent_checkpoint_restores_the_frozen_gru():

@@ -731,3 +731,62 @@ def test_value_saliency_matches_autograd(arch, precision):
     a2, l2, v2 = eng.predict_staged(obs_dev, seed=3)        # same staged prediction as the plain entry point
     assert np.array_equal(a2, act) and np.allclose(l2, logp, atol=1e-6) and np.allclose(v2, val, atol=1e-6)
     eng.close()
+
+
+@pytest.mark.parametrize("arch,precision", [("impala", "fp32"), ("impala", "bf16"), ("mlp", "fp32")])
+def test_value_saliency_through_the_gru_matches_autograd(arch, precision):
+    """predict_w_value_saliency for a RECURRENT policy (agents/ppo.py:83-94 -> CategoricalPolicy.forward -> GRU.forward's prediction branch,
+    common/model.py:219-225): value = fc_value(GRU(embedder(obs), hidden * (1 - done))), so d value / d obs runs back through the cell's
+    input path (gates r, z, n) before the embedder's backward pass.  Against torch autograd through oracle.gru_cell (pinned to the
+    reference's nn.GRU step by fixture G9) + the embedder oracle: value 2e-5, new hidden state 2e-5, gradient 2e-3 of its scale (fp32);
+    bf16 storage: direction (cos > 0.9).  One env has done = 1 (its hidden state is masked), and the step advances the engine's
+    hidden state like a policy step."""
+    from mi355 import layout
+    from mi355.engine import Engine
+    E, A = 4, (15 if arch == "impala" else 2)
+    params = golden_params(arch)
+    shapes = shapes_for(arch, A)
+    rng = np.random.default_rng(12)
+    H = 256 if arch == "impala" else 64
+    if arch == "impala":
+        eng = Engine("impala", 2, E, A, E, precision=precision)
+        obs_dev = rng.integers(0, 256, size=(E, 64, 64, 3), dtype=np.uint8)
+        x = O.frames_to_obs(obs_dev).clone().requires_grad_(True)
+    else:
+        eng = Engine("mlp", 2, E, A, E, obs_dim=9, mlp_depth=4, mlp_width=256, out_dim=64)
+        obs_dev = rng.standard_normal((E, 9)).astype(np.float32)
+        x = torch.from_numpy(obs_dev).clone().requires_grad_(True)
+    eng.set_params(layout.flatten(shapes, params))
+    k = 1.0 / np.sqrt(H)                                     # nn.GRU's default uniform init range
+    g = {"gru.gru.weight_ih_l0": rng.uniform(-k, k, (3 * H, H)), "gru.gru.weight_hh_l0": rng.uniform(-k, k, (3 * H, H)),
+         "gru.gru.bias_ih_l0": rng.uniform(-k, k, 3 * H), "gru.gru.bias_hh_l0": rng.uniform(-k, k, 3 * H)}
+    g = {n: v.astype(np.float32) for n, v in g.items()}
+    eng.set_gru(g["gru.gru.weight_ih_l0"], g["gru.gru.weight_hh_l0"], g["gru.gru.bias_ih_l0"], g["gru.gru.bias_hh_l0"])
+    hid = (0.5 * rng.standard_normal((E, H))).astype(np.float32)
+    done = np.array([0, 1, 0, 0], np.float32)
+    p = {n: torch.from_numpy(np.ascontiguousarray(v)) for n, v in {**params, **g}.items()}
+    feat = O.impala_embed(p, x)[0] if arch == "impala" else O.mlp_embed(p, x)
+    h_new = O.gru_cell(p, feat, torch.from_numpy(hid), torch.from_numpy(1.0 - done))
+    lp, v = O.heads(p, h_new)
+    v.sum().backward()
+    ref = x.grad.numpy()
+    eng.rec_state(hid, done)
+    act, logp, val, grad = eng.value_saliency(obs_dev, seed=3)
+    h_eng = eng.get_hidden()
+    if arch == "impala":
+        grad = grad.transpose(0, 3, 1, 2)
+    assert np.abs(ref).max() > 0
+    if precision == "fp32":
+        np.testing.assert_allclose(val, v.detach().numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(h_eng, h_new.detach().numpy(), rtol=0, atol=2e-5)
+        assert np.abs(grad - ref).max() < 2e-3 * np.abs(ref).max(), (np.abs(grad - ref).max(), np.abs(ref).max())
+    else:
+        cos = float((grad * ref).sum() / (np.linalg.norm(grad) * np.linalg.norm(ref) + 1e-30))
+        assert cos > 0.9, cos
+    assert not np.any(eng.get_grads())
+    # without the GRU's input path the gradient is a different one (the test is not vacuous)
+    lp0, v0 = O.heads(p, (O.impala_embed(p, x)[0] if arch == "impala" else O.mlp_embed(p, x)))
+    x.grad = None
+    v0.sum().backward()
+    assert np.abs(x.grad.numpy() - ref).max() > 0.1 * np.abs(ref).max()
+    eng.close()

@@ -161,8 +161,9 @@ class PPO(BaseAgent):
         """agents/ppo.py:83-94: predict + the gradient of the value with respect to the observation, in the observation's
         layout ((E,3,64,64) for frames).  Each env's value depends on its own observation only, so this is the gradient of
         sum_e value_e (the reference's value.backward() needs n_envs = 1, as render.py uses it)."""
-        if self.policy.is_recurrent():
-            raise NotImplementedError("value saliency through the GRU is not built")
+        rec = self.policy.is_recurrent()
+        if rec:                                                   # the value then depends on obs through the GRU cell as well (model.py:219-225)
+            self.engine.rec_state(hidden_state, done)
         self._predict_calls = getattr(self, "_predict_calls", 0) + 1
         act, logp, value, grad = self.engine.value_saliency(as_device_obs(obs, self.policy.arch),
                                                             seed=self.seed * 1000003 + self._iter,
@@ -170,7 +171,7 @@ class PPO(BaseAgent):
         self.storage.note_predicted(-1, obs, act, logp, value)
         if self.policy.arch == "impala":
             grad = np.ascontiguousarray(grad.transpose(0, 3, 1, 2))          # NHWC -> the reference's (E,3,64,64)
-        return act, logp, value, np.asarray(hidden_state), grad
+        return act, logp, value, (self.engine.get_hidden() if rec else np.asarray(hidden_state)), grad
 
     # ------------------------------------------------------------------ optimize
     def _hparams(self):

@@ -221,6 +221,7 @@ void launch_fill(float* p, long long n, float v, hipStream_t st);
 void launch_value_seed(float* dY, int n, int A, hipStream_t st);
 void launch_conv1_input_grad(const void* dC, int bf16, const float* W, float* dX, int n, hipStream_t st);
 void launch_mask_rows(const float* h, const float* done, float* out, int n, int H, hipStream_t st);   // out = h * (1 - done[row])
+void launch_gru_value_bwd(const float* gi, const float* gh, const float* hm, const float* wv, float* dgates, int n, int H, hipStream_t st);
 void launch_gru_gates(const float* gi, const float* gh, const float* hm, float* h_out, float* feat_out, int n, int H, hipStream_t st);
 
 // ---------------------------------------------------------------- embedder.fc on the bf16 matrix cores (fc_bf16.hip)

@@ -149,6 +149,7 @@ struct mi_ctx {
     int32_t* s_act; float *s_logp, *s_val; bool staged_valid;
     // recurrent rollout (GRU cell, never trained)
     bool gru_on; float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *h_state, *h_masked, *gru_gi, *gru_gh, *d_done;
+    float *gru_x, *gru_dg; bool sal_keep_x, bwd_from_dfeat;      // value saliency through the GRU: the cell's input (embedder output), d gates; net_backward starts at dfeat
     // pinned host staging
     // index staging ring: a slot is rewritten only after the H2D copy that read it has completed
     static constexpr int IDX_RING = 32;
@@ -440,6 +441,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         HIPC(hipMalloc((void**)&c->d_bank_desc, desc.size() * sizeof(BankDesc)));
         HIPC(hipMemcpy(c->d_bank_desc, desc.data(), desc.size() * sizeof(BankDesc), hipMemcpyHostToDevice));
     }
+    c->gru_x = c->gru_dg = nullptr; c->sal_keep_x = c->bwd_from_dfeat = false;
     c->gru_on = false; c->gru_wih = c->gru_whh = c->gru_bih = c->gru_bhh = c->h_state = c->h_masked = c->gru_gi = c->gru_gh = c->d_done = nullptr;
     HIPC(hipDeviceSynchronize());
     *out = c;
@@ -474,7 +476,7 @@ int mi_destroy(mi_ctx* c) {
     if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
     if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc); if (c->c1_bank) hipFree(c->c1_bank);
     hipFree(c->stats_ring); hipFree(c->fs_ring); hipFree(c->fs_parts); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd); hipFree(c->d_done_ctr); hipHostFree(c->h_flag);
-    { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done}; for (float* q : gr) if (q) hipFree(q); }
+    { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done, c->gru_x, c->gru_dg}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     if (c->fs_colmax) hipFree(c->fs_colmax); if (c->fs_arg) hipFree(c->fs_arg);
     if (c->fs_keys) hipFree(c->fs_keys); if (c->fs_keys_local) hipFree(c->fs_keys_local); if (c->d_gpos) hipFree(c->d_gpos); if (c->h_gpos) hipHostFree(c->h_gpos);
@@ -795,6 +797,7 @@ static void net_gru(mi_ctx* c, int n, int soff = 0) {
     launch_mask_rows(c->h_state + o, c->d_done + soff, c->h_masked + o, n, H, CUR(c));
     linear_fwd(c, c->feat + o, 0, c->gru_wih, c->gru_bih, c->gru_gi + 3 * o, n, H, 3 * H, 0);
     linear_fwd(c, c->h_masked + o, 0, c->gru_whh, c->gru_bhh, c->gru_gh + 3 * o, n, H, 3 * H, 0);
+    if (c->sal_keep_x) hipMemcpyAsync(c->gru_x + o, c->feat + o, (size_t)n * H * 4, hipMemcpyDeviceToDevice, CUR(c));     // (the gates kernel overwrites feat with h')
     launch_gru_gates(c->gru_gi + 3 * o, c->gru_gh + 3 * o, c->h_masked + o, c->h_state + o, c->feat + o, n, H, CUR(c));
 }
 
@@ -896,7 +899,9 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
 // backward from dY (n x (A+1)); gradients accumulate into c->grads
 static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
-    if (c->H <= 256 && c->A + 1 <= 16 && !tl_ws) {        // one launch (+ its slab sum) for the heads' three gradients (misc.hip: heads_bwd_kernel)
+    if (c->bwd_from_dfeat) {
+        // value saliency of a recurrent policy: c->dfeat already holds d value / d (embedder output) (through the GRU cell, mi_value_saliency)
+    } else if (c->H <= 256 && c->A + 1 <= 16 && !tl_ws) {        // one launch (+ its slab sum) for the heads' three gradients (misc.hip: heads_bwd_kernel)
         ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * (c->A + 1) + 2.0 * n * c->H + (double)c->H * (c->A + 1)), 4.0 * n * c->H * (c->A + 1));
         launch_heads_bwd(c->dY, c->feat, c->params + c->wh_off, impala ? 1 : 0, c->dfeat, c->grads + c->wh_off, c->grads + c->bh_off, c->gemm_ws,
                          n, c->H, c->A + 1, CUR(c));
@@ -1312,7 +1317,6 @@ int mi_predict_staged(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, u
 int mi_value_saliency(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, uint64_t counter, const float* u,
                       int64_t* act_out, float* logp_out, float* value_out, float* grad_out) {
     ARG(c && obs && grad_out, "null"); JOIN(c);
-    ARG(!c->gru_on, "value saliency through the GRU is not built");
     ARG(c->pending_n < 0, "a multirank minibatch is pending");
     const int E = c->E;
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
@@ -1323,11 +1327,25 @@ int mi_value_saliency(mi_ctx* c, const void* obs, size_t bytes, uint64_t seed, u
     if (u) { HIPC(hipMemcpyAsync(c->d_u, u, (size_t)E * 4, hipMemcpyHostToDevice, c->stream)); du = c->d_u; }
     InputSrc src{stage, nullptr, 0};
     c->prof.phase = 0;
-    net_forward(c, src, E, false, true, true);
+    const bool rec = c->gru_on;
+    if (rec && !c->gru_x) { HIPC(dalloc(&c->gru_x, (size_t)E * c->H)); HIPC(dalloc(&c->gru_dg, (size_t)E * 3 * c->H)); }
+    c->sal_keep_x = rec;
+    net_forward(c, src, E, rec, true, true);          // recurrent: h' = GRU(embedder output, h (1 - done)) as a policy step does, heads on h'
+    c->sal_keep_x = false;
     launch_sample(c->hout, E, c->A, du, seed, counter, c->s_act, c->s_logp, c->s_val, c->stream);
-    launch_value_seed(c->dY, E, c->A, c->stream);
     c->sal_src = nullptr;
-    net_backward(c, src, E);
+    if (rec) {
+        // value = w_v . h' + b_v: back through the GRU cell to its input x (common/model.py:219-225 under autograd, agents/ppo.py:88-89), then
+        // through the embedder's final ReLU (IMPALA) -- d value / d x = dgates W_ih -- and on down the usual backward pass from dfeat
+        launch_gru_value_bwd(c->gru_gi, c->gru_gh, c->h_masked, c->params + c->wh_off + (size_t)c->A * c->H, c->gru_dg, E, c->H, c->stream);
+        linear_dgrad(c, c->gru_dg, c->gru_wih, impala ? c->gru_x : nullptr, c->dfeat, E, c->H, 3 * c->H);
+        c->bwd_from_dfeat = true;
+        net_backward(c, src, E);
+        c->bwd_from_dfeat = false;
+    } else {
+        launch_value_seed(c->dY, E, c->A, c->stream);
+        net_backward(c, src, E);
+    }
     ARG(c->sal_src, "backward did not reach the first layer");
     const size_t gfloats = impala ? (size_t)E * 64 * 64 * 3 : (size_t)E * c->cfg.obs_dim;
     if (!c->sal_dx) HIPC(dalloc(&c->sal_dx, impala ? (size_t)c->NB * 64 * 64 * 3 : (size_t)c->NB * c->cfg.obs_dim));

@@ -1468,6 +1468,29 @@ __global__ void gru_gates_kernel(const float* gi, const float* gh, const float* 
     h_out[e] = hn;
     feat_out[e] = hn;
 }
+// d value / d (GRU input pre-activations): value = w_v . h' + b_v with h' = (1 - z) n + z h (gates as in gru_gates_kernel), so with
+// g = w_v[j]:  dn = g (1 - z), dz = g (h - n);  d pre_n = dn (1 - n^2), d pre_z = dz z (1 - z), d pre_r = d pre_n gh_n r (1 - r).
+// dgates[row] = {d pre_r, d pre_z, d pre_n} (3H): the gradient wrt gi = W_ih x + b_ih; dx = dgates W_ih follows as a GEMM.
+__global__ void gru_value_bwd_kernel(const float* gi, const float* gh, const float* hm, const float* wv, float* dgates, int n, int H) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * H) return;
+    const int row = e / H, j = e % H;
+    const float* a = gi + (long long)row * 3 * H;
+    const float* b = gh + (long long)row * 3 * H;
+    const float r = 1.f / (1.f + expf(-(a[j] + b[j])));
+    const float z = 1.f / (1.f + expf(-(a[H + j] + b[H + j])));
+    const float nn = tanhf(a[2 * H + j] + r * b[2 * H + j]);
+    const float g = wv[j];
+    const float dpn = g * (1.f - z) * (1.f - nn * nn);
+    const float dpz = g * (hm[e] - nn) * z * (1.f - z);
+    const float dpr = dpn * b[2 * H + j] * r * (1.f - r);
+    float* d = dgates + (long long)row * 3 * H;
+    d[j] = dpr; d[H + j] = dpz; d[2 * H + j] = dpn;
+}
+void launch_gru_value_bwd(const float* gi, const float* gh, const float* hm, const float* wv, float* dgates, int n, int H, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gru_value_bwd_kernel, dim3((n * H + 255) / 256), dim3(256), 0, st, gi, gh, hm, wv, dgates, n, H);
+}
 void launch_gru_gates(const float* gi, const float* gh, const float* hm, float* h_out, float* feat_out, int n, int H, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(gru_gates_kernel, dim3((n * H + 255) / 256), dim3(256), 0, st, gi, gh, hm, h_out, feat_out, n, H);
