@@ -42,6 +42,13 @@ int main(int argc, char** argv) {
     double s2 = 0, s1 = 0; for (size_t k = 0; k < (size_t)grid * 2320; ++k) { s2 += hs[k]; s1 += hs[(size_t)grid * 2320 + k]; }
     printf("n=%d grid=%d: %.1f us/launch  dx fnv %016llx  slab sums %.6e %.6e  (%s)\n", n, grid, ms * 1000 / reps, cx, s2, s1, hipGetErrorString(hipGetLastError()));
 #ifdef RBF_TIMING
+    if (RBFULL16_SPECIALISED) {
+        unsigned long long t[8]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_rbf_timing), sizeof t);
+        const char* nm[4] = {"staging (+wait)", "phase-1 work", "wait at mid barrier", "phase-2 work + top wait"};
+        const double items = (double)n * RbFull16S::TPI / grid * reps;
+        for (int role = 0; role < 2; ++role)
+            for (int k = 0; k < 4; ++k) printf("  %s %-24s %8.0f cycles per item\n", role ? "wgrad" : "conv ", nm[k], (double)t[role * 4 + k] / grid / items);
+    } else
     {   // slot k = cycles between mark k-1 and mark k of wave 0 (slot 0: weight-gradient phase of the previous item + loop back)
         unsigned long long t[8]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_rbf_timing), sizeof t);
         const char* nm[8] = {"wgrad phase (prev item)", "wait top barrier", "stage tiles to LDS", "wait barrier", "issue next loads", "phase A conv (da)", "wait mid barrier", "phase B conv (dx)"};

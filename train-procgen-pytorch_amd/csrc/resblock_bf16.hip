@@ -890,7 +890,551 @@ __global__ __launch_bounds__(RbFull::NT, RbFull::NT == 512 ? 4 : 2) void resbloc
     }
     }
 }
+// ---- wave-specialised variant of the kernel above (16 channels @32x32, 512 threads, ONE workgroup per CU).
+// scratch/kbench_rb16.hip phase clocks of the kernel above: conv phases A + B = 54 % of an item's cycles with the matrix pipe 28 % and the
+// LDS pipe 48 % busy -- every wave walks load-issue -> LDS stores -> conv A -> conv B -> weight gradients one after the other, two
+// waves per SIMD, each phase waiting on its own LDS / MFMA latencies.  Here, as in resblock_bwd_full32s_bf16_kernel, the eight waves take two
+// ROLES and each SIMD hosts one wave of each, so the matrix work of one role overlaps the LDS work of the other:
+//   waves 0-3  the two transposed convs, BOTH filter banks in registers (2 x 5 fragments = 40 VGPRs, loaded once per launch: no weight
+//              reads from LDS, no bank copies in LDS); a wave's operand reads of a whole phase go out before its first MFMA;
+//   waves 4-7  global loads + LDS staging of the tiles (four 16-byte words per thread and tensor row group, one index space), conv2's
+//              weight gradient while the conv waves produce da, conv1's while they produce dx -- two CONSECUTIVE pixel rows per wave and
+//              quarter tile, operand rows shared between them.
+// Arithmetic per output element is unchanged (same K order): dx / da are bit-identical to the kernel above; weight-gradient slabs sum
+// the same products (rows dealt to other waves).
+template <int TH_>
+struct RbFull16ST {
+    static constexpr int C = 16, HW = 32, TH = TH_, NT = 512, S = 16, P = HW + 2, TPI = HW / TH;
+    static constexpr int XR = TH + 4, YR = TH + 2;
+    static constexpr int X_ELEMS = XR * P * S, Y_ELEMS = YR * P * S;
+    static constexpr int NK = 5, WS = NK * 32 + 16;
+    static constexpr int NMT1 = YR * HW / 16, NMT2 = TH * HW / 16, MT1 = (NMT1 + 3) / 4, MT2 = NMT2 / 4;       // tiles per conv wave
+    static constexpr int NX = XR * HW * 2, NA = YR * HW * 2, NWORD = NX + 2 * NA, KW = (NWORD + 255) / 256;    // 16-byte words; per staging thread
+    static constexpr int NR = TH / 4;                                                                       // pixel rows per weight-gradient wave
+    static constexpr int WLEN = C * 9 * C, SLAB = WLEN + C;
+    static constexpr size_t TILE_BYTES = (size_t)(X_ELEMS + 3 * Y_ELEMS) * 2, RED_BYTES = (size_t)(2 * WLEN + 2 * 4 * C) * 4;
+    static constexpr size_t LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
+    static_assert(NMT2 % 4 == 0 && TH % 4 == 0, "whole tiles / rows per wave");
+};
+#ifndef RBFULL16S_TH
+#define RBFULL16S_TH 8
+#endif
+#ifndef RBFULL16S_CG
+#define RBFULL16S_CG 2
+#endif
+using RbFull16S = RbFull16ST<RBFULL16S_TH>;
+
+__global__ __launch_bounds__(512, 2) void resblock_bwd_full16s_bf16_kernel(RbFullArgs a) {
+    using C = RbFull16S;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_x = smem_h;                         // dy rows ty0-2 .. ty0+TH+1
+    unsigned short* s_y = s_x + C::X_ELEMS;               // d(conv1 output) rows ty0-1 .. ty0+TH
+    unsigned short* s_a = s_y + C::Y_ELEMS;               // relu(conv1 output), same rows
+    unsigned short* s_p = s_a + C::Y_ELEMS;               // relu(block input), same rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool conv_role = wv < 4;
+    const int rw = wv & 3;
+#ifdef RBF_TIMING
+    long long tacc_[4] = {0, 0, 0, 0}, tlast_ = clock64();
+#define S16_TCK(k) do { if ((tid & 255) == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
+#else
+#define S16_TCK(k) do { } while (0)
+#endif
+    for (int e = tid; e < (C::X_ELEMS + 3 * C::Y_ELEMS) / 8; e += C::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
+    // ONE register array for both roles (two sets: the kernel's allocation is the union of what its waves may keep live).
+    // conv role: st[m] = fragment of K step m of conv2's transposed bank, st[5 + m] of conv1's.
+    // weight-gradient role: st[tap] / st[10 + tap] accumulator tiles of conv2 / conv1, st[9] / st[19] their bias rows, st[20 ..] the prefetch words.
+    constexpr int NST = 20 + C::KW;
+    f32x4 st[NST];
+    if (conv_role) {
+#pragma unroll
+        for (int m = 0; m < C::NK; ++m) {
+            st[m] = __builtin_bit_cast(f32x4, *(const uint4*)(a.bank2_t + i * C::WS + m * 32 + kq * 8));
+            st[5 + m] = __builtin_bit_cast(f32x4, *(const uint4*)(a.bank1_t + i * C::WS + m * 32 + kq * 8));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NST; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the bank fragments are in (see resblock_bwd_full32s_bf16_kernel)
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    int koff[C::NK];
+#pragma unroll
+    for (int m = 0; m < C::NK; ++m) {
+        int tap = 2 * m + (kq >> 1); const int chunk = kq & 1; if (tap > 8) tap = 8;
+        koff[m] = ((tap / 3) * C::P + (tap % 3)) * C::S + chunk * 8;
+    }
+    constexpr int CG = RBFULL16S_CG;                       // conv tiles whose operand reads are in flight together
+    const int nwork = a.n * C::TPI;
+    const int t2 = tid - 256;                              // staging thread index (weight-gradient waves)
+    auto word = [&](int e, int& t, int& le) { t = e < C::NX ? 0 : (e < C::NX + C::NA ? 1 : 2); le = e - (t == 0 ? 0 : (t == 1 ? C::NX : C::NX + C::NA)); };
+    auto load = [&](int work) {                            // unconditional, clamped (replaced by zeros at the store where outside the image)
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+#pragma unroll
+        for (int k = 0; k < C::KW; ++k) {
+            int e = t2 + k * 256; e = e < C::NWORD ? e : C::NWORD - 1;
+            int t, le; word(e, t, le);
+            const int c8 = le & 1, px = (le >> 1) % C::HW; int gy = ty0 - (t == 0 ? 2 : 1) + le / (2 * C::HW);
+            gy = gy < 0 ? 0 : (gy > C::HW - 1 ? C::HW - 1 : gy);
+            const unsigned short* src = t == 0 ? a.dy : (t == 1 ? a.a_fwd : a.x_fwd);
+            st[20 + k] = __builtin_bit_cast(f32x4, *(const uint4*)(src + ((img * C::HW + gy) * C::HW + px) * C::C + c8 * 8));
+        }
+    };
+    auto item = [&](int w) { return w < nwork ? w : nwork - 1; };
+    // weight gradient of one layer over this wave's NR consecutive pixel rows: d = output-gradient tile (row offset d_row), b = input tile
+    auto wgrad = [&](const unsigned short* s_d, int d_row, const unsigned short* s_b, const int a0) {
+        const int r0 = C::NR * rw;
+        int ocol[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) ocol[h] = (16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq) * C::S + 4 * cp;
+        auto tr = [&](const unsigned short* base, int off) {
+            const rb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + ocol[0] + off));
+            const rb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + ocol[1] + off));
+            return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8 dd[C::NR];
+#pragma unroll
+        for (int j = 0; j < C::NR; ++j) dd[j] = tr(s_d, ((r0 + j + d_row) * C::P + 1) * C::S);
+#pragma unroll
+        for (int j = 0; j < C::NR; ++j) st[a0 + 9] = MFMA_BF16(dd[j], ones, st[a0 + 9]);
+#pragma unroll
+        for (int R = 0; R < C::NR + 2; ++R) {                // tile row r0 + R of the input tile (row 0 = ty0-1, col 0 = -1)
+            bf16x8 fb[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) fb[kx] = tr(s_b, ((r0 + R) * C::P + kx) * C::S);
+#pragma unroll
+            for (int j = 0; j < C::NR; ++j) {
+                const int ky = R - j;
+                if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) st[a0 + ky * 3 + kx] = MFMA_BF16(dd[j], fb[kx], st[a0 + ky * 3 + kx]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (!conv_role && (int)blockIdx.x < nwork) load(blockIdx.x);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+        __syncthreads();
+        S16_TCK(3);                                         // phase-2 work + wait at the top barrier
+        if (!conv_role) {
+#pragma unroll
+            for (int k = 0; k < C::KW; ++k) {
+                const int e = t2 + k * 256;
+                int t, le; word(e < C::NWORD ? e : C::NWORD - 1, t, le);
+                const int ry = le / (2 * C::HW), gy = ty0 - (t == 0 ? 2 : 1) + ry;
+                const bool in = gy >= 0 && gy < C::HW;
+                unsigned short* dst = (t == 0 ? s_x : (t == 1 ? s_a : s_p)) + (ry * C::P + (le >> 1) % C::HW + 1) * C::S + (le & 1) * 8;
+                const uint4 v = __builtin_bit_cast(uint4, st[20 + k]);
+                const uint4 r = t == 0 ? v : (uint4){rb_relu2(v.x), rb_relu2(v.y), rb_relu2(v.z), rb_relu2(v.w)};
+                if (e < C::NWORD) *(uint4*)dst = in ? r : (uint4){0u, 0u, 0u, 0u};
+            }
+        }
+        __syncthreads();
+        S16_TCK(0);                                         // staging (+ the conv waves' wait for it)
+        if (!conv_role) load(item(work + gridDim.x));
+
+        if (conv_role) {
+            // ---- da = convT2(dy) * (a > 0) on rows ty0-1 .. ty0+TH -> s_y: tiles rw, rw+4, ... in groups of CG: a group's operand reads go
+            // out together, then its MFMAs (K-step-major: the accumulator chains of the group interleave)
+#pragma unroll
+            for (int g0 = 0; g0 < C::MT1; g0 += CG) {
+                bf16x8 av[CG][C::NK];
+                uint2 mk[CG];
+                int yb[CG];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    const int mt = g0 + q < C::MT1 ? g0 + q : C::MT1 - 1;
+                    int t = rw + 4 * mt; t = t < C::NMT1 ? t : C::NMT1 - 1;            // (a clamped duplicate rewrites the same values)
+                    const int pl = t * 16 + i, px = pl % C::HW, ry = pl / C::HW;
+                    const unsigned short* src = s_x + (ry * C::P + px) * C::S;
+                    yb[q] = (ry * C::P + px + 1) * C::S + kq * 4;
+#pragma unroll
+                    for (int m = 0; m < C::NK; ++m) av[q][m] = *(const bf16x8*)(src + koff[m]);
+                    mk[q] = *(const uint2*)(s_a + yb[q]);
+                }
+                f32x4 acc[CG];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < C::NK; ++m)
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) acc[q] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[m]), av[q][m], acc[q]);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rb_lane(mk[q], r) > 0.f ? acc[q][r] : 0.f;
+                    const uint2 raw = rb_pack(v);
+                    *(uint2*)(s_y + yb[q]) = raw;
+                    if (a.da_out) {
+                        const int mt = g0 + q < C::MT1 ? g0 + q : C::MT1 - 1;
+                        int t = rw + 4 * mt; t = t < C::NMT1 ? t : C::NMT1 - 1;
+                        const int pl = t * 16 + i, px = pl % C::HW, ry = pl / C::HW, gy = ty0 - 1 + ry;
+                        if (ry >= 1 && ry <= C::TH) *(uint2*)(a.da_out + ((img * C::HW + gy) * C::HW + px) * C::C + kq * 4) = raw;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);            // (register budget: the next group's reads stay behind this group's epilogue)
+            }
+        } else {
+            wgrad(s_x, 2, s_a, 0);                           // conv2's weight / bias gradient from (dy, relu(a)): nothing the conv waves are producing
+        }
+        S16_TCK(1);                                         // phase-1 work
+        __syncthreads();
+        S16_TCK(2);                                         // wait for the other role
+        if (conv_role) {
+            // ---- dx = convT1(da) * (x > 0) + dy on rows ty0 .. ty0+TH-1 -> HBM
+            static_assert(C::MT2 % CG == 0, "whole groups");
+#pragma unroll
+            for (int g0 = 0; g0 < C::MT2; g0 += CG) {
+                bf16x8 av[CG][C::NK];
+                uint2 mk[CG], sk[CG];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    const int pl = (rw + 4 * (g0 + q)) * 16 + i, px = pl % C::HW, oy = pl / C::HW;
+                    const unsigned short* src = s_y + (oy * C::P + px) * C::S;
+#pragma unroll
+                    for (int m = 0; m < C::NK; ++m) av[q][m] = *(const bf16x8*)(src + koff[m]);
+                    mk[q] = *(const uint2*)(s_p + ((oy + 1) * C::P + px + 1) * C::S + kq * 4);
+                    sk[q] = *(const uint2*)(s_x + ((oy + 2) * C::P + px + 1) * C::S + kq * 4);
+                }
+                f32x4 acc[CG];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < C::NK; ++m)
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) acc[q] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[5 + m]), av[q][m], acc[q]);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    const int pl = (rw + 4 * (g0 + q)) * 16 + i, px = pl % C::HW, oy = pl / C::HW;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (rb_lane(mk[q], r) > 0.f ? acc[q][r] : 0.f) + rb_lane(sk[q], r);
+                    *(uint2*)(a.dx_out + ((img * C::HW + ty0 + oy) * C::HW + px) * C::C + kq * 4) = rb_pack(v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            wgrad(s_y, 1, s_p, 10);                          // conv1's weight / bias gradient from (da, relu(x))
+        }
+    }
+#ifdef RBF_TIMING
+    if ((tid & 255) == 0) for (int q = 0; q < 4; ++q) atomicAdd(&g_rbf_timing[(tid >> 8) * 4 + q], (unsigned long long)tacc_[q]);
+#endif
+    // ---- the four weight-gradient waves summed through LDS in wave order; one slab per workgroup and layer
+    __syncthreads();
+    float* red = (float*)smem_h;                              // [2][WLEN] then [2][4][16] bias partials
+    float* redb = red + 2 * C::WLEN;
+    for (int w = 0; w < 4; ++w) {
+        if (!conv_role && rw == w) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = ((kq * 4 + r) * 9 + tap) * C::C + i;
+                    red[o] = (w == 0) ? st[tap][r] : red[o] + st[tap][r];
+                    red[C::WLEN + o] = (w == 0) ? st[10 + tap][r] : red[C::WLEN + o] + st[10 + tap][r];
+                }
+        }
+        __syncthreads();
+    }
+    if (!conv_role && i == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { redb[rw * 16 + kq * 4 + r] = st[9][r]; redb[4 * 16 + rw * 16 + kq * 4 + r] = st[19][r]; }
+    }
+    __syncthreads();
+    float* sl2 = a.slab2 + (long long)blockIdx.x * C::SLAB;
+    float* sl1 = a.slab1 + (long long)blockIdx.x * C::SLAB;
+    for (int e = tid; e < C::WLEN; e += C::NT) { sl2[e] = red[e]; sl1[e] = red[C::WLEN + e]; }
+    if (tid < 16) {
+        float t2s = 0.f, t1s = 0.f;
+        for (int w = 0; w < 4; ++w) { t2s += redb[w * 16 + tid]; t1s += redb[4 * 16 + w * 16 + tid]; }
+        sl2[C::WLEN + tid] = t2s; sl1[C::WLEN + tid] = t1s;
+    }
+}
+// ---- the same two roles with the tiles filled by LDS-DMA into TWO tile buffers (RBFULL16_SPECIALISED == 2).
+// Phase clocks of the kernel above (scratch/kbench_rb16.hip): 28 % of an item is "staging" -- the weight-gradient waves wait for their
+// prefetched words, apply the ReLU and write 8 x 16 bytes per thread to LDS while the conv waves idle.  A row of a tile is 32 pixels x 32
+// bytes = 1 KB, contiguous in HBM (NHWC) and in LDS: exactly ONE global_load_lds_dwordx4 wave-instruction (lane = 16-byte word of the
+// row), no registers, no LDS store instructions.  So: two tile buffers (2 x 45 KB); at the top of item k the weight-gradient waves issue the
+// 32 row DMAs of item k + 1 into the other buffer (a whole item of flight time), drain them (vmcnt(0)) just before the item's last barrier.
+// What changes for the consumers: relu(a) / relu(x) are no longer applied while staging -- the tiles hold RAW a and x; the ReLU masks
+// read them as before (> 0 is the same truth), the weight-gradient operand fragments take the ReLU in registers (one v_pk_max_i16 per
+// dword: max(x, 0) on bf16 bits = the staged relu, -0 -> +0 included).  Rows outside the image (first / last item of an image) are
+// zero-filled with one 16-byte LDS store per lane by the wave that would have issued their DMA.  Two barriers per item instead of three,
+// both raw (s_waitcnt lgkmcnt(0) + s_barrier): a __syncthreads() would also wait for the conv waves' dx stores.
+// The DMAs are issued from inline asm (the compiler, seeing an LDS write it cannot place, would wait for a builtin's load before the next
+// LDS read of the issuing wave): M0 is set in the same statement, the waits are explicit, and the kernel drains its last prefetch before exit.
+__device__ __forceinline__ void rb_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void rb_raw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N> __device__ __forceinline__ void rb_wait_vm() { static_assert(N >= 0 && N < 64, "vmcnt"); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ unsigned short g_rb_zero_row[64 * 512];     // 64 x 1 KB of zeros: the DMA source of tile rows outside the image (one per workgroup mod 64:
+                                                        // every workgroup reading the SAME 1 KB hit one L2 channel -- 352 vs 338 us per launch)
+#ifndef RBFULL16D_NBUF
+#define RBFULL16D_NBUF 3
+#endif
+#ifndef RBFULL16D_CG
+#define RBFULL16D_CG 5
+#endif
+#ifndef RBFULL16D_NC
+#define RBFULL16D_NC 0             // tile rows (of 32) whose DMA each conv wave issues (measured: 0 best -- 338 us; 2 / 3 / 4: 374-387 / 376-380 / 365-371)
+#endif
+__global__ __launch_bounds__(512, 2) void resblock_bwd_full16d_bf16_kernel(RbFullArgs a) {
+    using C = RbFull16S;
+    constexpr int TILE = C::X_ELEMS + 3 * C::Y_ELEMS;       // elements of one tile buffer: s_x, s_y, s_a, s_p
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool conv_role = wv < 4;
+    const int rw = wv & 3;
+#ifdef RBF_TIMING
+    long long tacc_[4] = {0, 0, 0, 0}, tlast_ = clock64();
+#endif
+    constexpr int NBUF = RBFULL16D_NBUF;                    // tile buffers: item k computes in buffer k % NBUF while the rows of items k+1 .. k+NBUF-1 are in flight / landed
+    for (int e = tid; e < NBUF * TILE / 8; e += C::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos of all buffers stay zero
+    constexpr int NST = 20;
+    f32x4 st[NST];                                          // conv role: st[m] / st[5 + m] bank fragments; weight-gradient role: accumulators (as above)
+    if (conv_role) {
+#pragma unroll
+        for (int m = 0; m < C::NK; ++m) {
+            st[m] = __builtin_bit_cast(f32x4, *(const uint4*)(a.bank2_t + i * C::WS + m * 32 + kq * 8));
+            st[5 + m] = __builtin_bit_cast(f32x4, *(const uint4*)(a.bank1_t + i * C::WS + m * 32 + kq * 8));
+        }
+#pragma unroll
+        for (int q = 10; q < NST; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int q = 0; q < NST; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the bank fragments are in
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    int koff[C::NK];
+#pragma unroll
+    for (int m = 0; m < C::NK; ++m) {
+        int tap = 2 * m + (kq >> 1); const int chunk = kq & 1; if (tap > 8) tap = 8;
+        koff[m] = ((tap / 3) * C::P + (tap % 3)) * C::S + chunk * 8;
+    }
+    constexpr int CG = RBFULL16D_CG;
+    const int nwork = a.n * C::TPI;
+    const unsigned lds0 = (unsigned)(unsigned long long)(void*)smem_h;          // LDS byte address of the tile buffers (low half of the flat address)
+    auto item = [&](int w) { return w < nwork ? w : nwork - 1; };
+    // the 32 tile rows of item `work` -> buffer b, rows rw, rw + 4, ... by this (weight-gradient) wave: a DMA per row inside the image, zeros otherwise
+    // (issuing one row costs its wave ~150 cycles -- 1 KB through the CU's load path -- so the rows are dealt to BOTH roles: NC per conv
+    //  wave, the rest to the weight-gradient waves, whose phases are the shorter ones)
+    constexpr int NROW = C::XR + 2 * C::YR, NC = RBFULL16D_NC, NWR = (NROW - 4 * NC + 3) / 4;
+    auto fill = [&](int work, int b) {
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+#pragma unroll
+        for (int jj = 0; jj < (NC > NWR ? NC : NWR); ++jj) {
+            if (jj >= (conv_role ? NC : NWR)) continue;     // (wave-uniform)
+            const int j = conv_role ? 4 * NWR + rw + 4 * jj : rw + 4 * jj;
+            if (j >= NROW) continue;
+            const int t = j < C::XR ? 0 : (j < C::XR + C::YR ? 1 : 2), ry = j - (t == 0 ? 0 : (t == 1 ? C::XR : C::XR + C::YR));
+            const int gy = ty0 - (t == 0 ? 2 : 1) + ry;
+            // element offset of the row's first interior pixel inside the buffer: s_x | s_y | s_a | s_p
+            const int eoff = (t == 0 ? 0 : (t == 1 ? C::X_ELEMS + C::Y_ELEMS : C::X_ELEMS + 2 * C::Y_ELEMS)) + (ry * C::P + 1) * C::S;
+            // a row outside the image comes from a row of zeros: every wave then issues the SAME number of DMAs per item, so the counted
+            // wait for "all but the younger items' rows" is an immediate
+            const unsigned short* src = (gy >= 0 && gy < C::HW) ? (t == 0 ? a.dy : (t == 1 ? a.a_fwd : a.x_fwd)) + ((img * C::HW + gy) * C::HW) * C::C + lane * 8
+                                                                : g_rb_zero_row + (blockIdx.x & 63) * 512 + lane * 8;
+            rb_glds16(src, lds0 + (unsigned)(b * TILE + eoff) * 2u);
+        }
+    };
+    auto relu8 = [](bf16x8 v) {
+        const uint4 u = __builtin_bit_cast(uint4, v);
+        return __builtin_bit_cast(bf16x8, (uint4){rb_relu2_max(u.x), rb_relu2_max(u.y), rb_relu2_max(u.z), rb_relu2_max(u.w)});
+    };
+    // weight gradient of one layer over this wave's NR consecutive pixel rows: d = output-gradient tile (row offset d_row), b = RAW input tile
+    auto wgrad = [&](const unsigned short* s_d, int d_row, const unsigned short* s_b, const int a0) {
+        const int r0 = C::NR * rw;
+        int ocol[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) ocol[h] = (16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq) * C::S + 4 * cp;
+        auto tr = [&](const unsigned short* base, int off) {
+            const rb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + ocol[0] + off));
+            const rb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + ocol[1] + off));
+            return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8 dd[C::NR];
+#pragma unroll
+        for (int j = 0; j < C::NR; ++j) dd[j] = tr(s_d, ((r0 + j + d_row) * C::P + 1) * C::S);
+#pragma unroll
+        for (int j = 0; j < C::NR; ++j) st[a0 + 9] = MFMA_BF16(dd[j], ones, st[a0 + 9]);
+#pragma unroll
+        for (int R = 0; R < C::NR + 2; ++R) {
+            bf16x8 fb[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) fb[kx] = relu8(tr(s_b, ((r0 + R) * C::P + kx) * C::S));
+#pragma unroll
+            for (int j = 0; j < C::NR; ++j) {
+                const int ky = R - j;
+                if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) st[a0 + ky * 3 + kx] = MFMA_BF16(dd[j], fb[kx], st[a0 + ky * 3 + kx]);
+            }
+        }
+    };
+
+    rb_raw_barrier();                                       // the zero fill is in
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d) fill(item(blockIdx.x + d * gridDim.x), d);
+    // rows of the first item landed: all but the (NBUF - 2) x rows-per-wave youngest DMAs of this wave
+    if (conv_role) rb_wait_vm<(NBUF - 2) * NC>(); else rb_wait_vm<(NBUF - 2) * NWR>();
+    rb_raw_barrier();
+    int b = 0;
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x, b = (b + 1 == NBUF ? 0 : b + 1)) {
+        const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+        unsigned short* s_x = smem_h + b * TILE;
+        unsigned short* s_y = s_x + C::X_ELEMS;
+        unsigned short* s_a = s_y + C::Y_ELEMS;
+        unsigned short* s_p = s_a + C::Y_ELEMS;
+        S16_TCK(3);                                         // (phase-2 work + wait at the end barrier of the previous item)
+        fill(item(work + (NBUF - 1) * gridDim.x), (b + NBUF - 1) % NBUF);      // that buffer's readers (item k - 1) finished before the barrier that ended the previous item
+        S16_TCK(0);                                         // DMA issue
+        if (conv_role) {
+            // ---- da = convT2(dy) * (a > 0) on rows ty0-1 .. ty0+TH -> s_y
+#pragma unroll
+            for (int g0 = 0; g0 < C::MT1; g0 += CG) {
+                bf16x8 av[CG][C::NK];
+                uint2 mk[CG];
+                int yb[CG];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    const int mt = g0 + q < C::MT1 ? g0 + q : C::MT1 - 1;
+                    int t = rw + 4 * mt; t = t < C::NMT1 ? t : C::NMT1 - 1;            // (a clamped duplicate rewrites the same values)
+                    const int pl = t * 16 + i, px = pl % C::HW, ry = pl / C::HW;
+                    const unsigned short* src = s_x + (ry * C::P + px) * C::S;
+                    yb[q] = (ry * C::P + px + 1) * C::S + kq * 4;
+#pragma unroll
+                    for (int m = 0; m < C::NK; ++m) av[q][m] = *(const bf16x8*)(src + koff[m]);
+                    mk[q] = *(const uint2*)(s_a + yb[q]);
+                }
+                f32x4 acc[CG];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < C::NK; ++m)
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) acc[q] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[m]), av[q][m], acc[q]);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rb_lane(mk[q], r) > 0.f ? acc[q][r] : 0.f;
+                    const uint2 raw = rb_pack(v);
+                    *(uint2*)(s_y + yb[q]) = raw;
+                    if (a.da_out) {
+                        const int mt = g0 + q < C::MT1 ? g0 + q : C::MT1 - 1;
+                        int t = rw + 4 * mt; t = t < C::NMT1 ? t : C::NMT1 - 1;
+                        const int pl = t * 16 + i, px = pl % C::HW, ry = pl / C::HW, gy = ty0 - 1 + ry;
+                        if (ry >= 1 && ry <= C::TH) *(uint2*)(a.da_out + ((img * C::HW + gy) * C::HW + px) * C::C + kq * 4) = raw;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            wgrad(s_x, 2, s_a, 0);                           // conv2's weight / bias gradient from (dy, relu(a))
+        }
+        S16_TCK(1);                                         // phase-1 work
+        rb_raw_barrier();                                   // da is complete (LDS only: the DMAs of the next item stay in flight)
+        S16_TCK(2);
+        if (conv_role) {
+            // ---- dx = convT1(da) * (x > 0) + dy on rows ty0 .. ty0+TH-1 -> HBM
+            constexpr int CG2 = C::MT2 % CG == 0 ? CG : (C::MT2 % 2 == 0 ? 2 : 1);
+#pragma unroll
+            for (int g0 = 0; g0 < C::MT2; g0 += CG2) {
+                bf16x8 av[CG2][C::NK];
+                uint2 mk[CG2], sk[CG2];
+#pragma unroll
+                for (int q = 0; q < CG2; ++q) {
+                    const int pl = (rw + 4 * (g0 + q)) * 16 + i, px = pl % C::HW, oy = pl / C::HW;
+                    const unsigned short* src = s_y + (oy * C::P + px) * C::S;
+#pragma unroll
+                    for (int m = 0; m < C::NK; ++m) av[q][m] = *(const bf16x8*)(src + koff[m]);
+                    mk[q] = *(const uint2*)(s_p + ((oy + 1) * C::P + px + 1) * C::S + kq * 4);
+                    sk[q] = *(const uint2*)(s_x + ((oy + 2) * C::P + px + 1) * C::S + kq * 4);
+                }
+                f32x4 acc[CG2];
+#pragma unroll
+                for (int q = 0; q < CG2; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < C::NK; ++m)
+#pragma unroll
+                    for (int q = 0; q < CG2; ++q) acc[q] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[5 + m]), av[q][m], acc[q]);
+#pragma unroll
+                for (int q = 0; q < CG2; ++q) {
+                    const int pl = (rw + 4 * (g0 + q)) * 16 + i, px = pl % C::HW, oy = pl / C::HW;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (rb_lane(mk[q], r) > 0.f ? acc[q][r] : 0.f) + rb_lane(sk[q], r);
+                    *(uint2*)(a.dx_out + ((img * C::HW + ty0 + oy) * C::HW + px) * C::C + kq * 4) = rb_pack(v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // this wave's row DMAs are older than its MT2 dx stores and the counter retires in order: all but the MT2 youngest done = rows landed
+            static_assert(C::MT2 == 4, "counted wait below");
+            rb_wait_vm<(NBUF - 2) * NC + 4>();
+        } else {
+            wgrad(s_y, 1, s_p, 10);                          // conv1's weight / bias gradient from (da, relu(x))
+            rb_wait_vm<(NBUF - 2) * NWR>();                  // the NEXT item's rows have landed: all but the rows of the items after it
+        }
+        rb_raw_barrier();                                   // everyone is done with this buffer; the other one is complete
+    }
+#ifdef RBF_TIMING
+    if ((tid & 255) == 0) for (int q = 0; q < 4; ++q) atomicAdd(&g_rbf_timing[(tid >> 8) * 4 + q], (unsigned long long)tacc_[q]);
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (prefetches past the last item: nothing may land in LDS after this workgroup is gone)
+    rb_raw_barrier();
+    // ---- the four weight-gradient waves summed through LDS in wave order; one slab per workgroup and layer
+    float* red = (float*)smem_h;                              // [2][WLEN] then [2][4][16] bias partials
+    float* redb = red + 2 * C::WLEN;
+    for (int w = 0; w < 4; ++w) {
+        if (!conv_role && rw == w) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = ((kq * 4 + r) * 9 + tap) * C::C + i;
+                    red[o] = (w == 0) ? st[tap][r] : red[o] + st[tap][r];
+                    red[C::WLEN + o] = (w == 0) ? st[10 + tap][r] : red[C::WLEN + o] + st[10 + tap][r];
+                }
+        }
+        __syncthreads();
+    }
+    if (!conv_role && i == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { redb[rw * 16 + kq * 4 + r] = st[9][r]; redb[4 * 16 + rw * 16 + kq * 4 + r] = st[19][r]; }
+    }
+    __syncthreads();
+    float* sl2 = a.slab2 + (long long)blockIdx.x * C::SLAB;
+    float* sl1 = a.slab1 + (long long)blockIdx.x * C::SLAB;
+    for (int e = tid; e < C::WLEN; e += C::NT) { sl2[e] = red[e]; sl1[e] = red[C::WLEN + e]; }
+    if (tid < 16) {
+        float t2s = 0.f, t1s = 0.f;
+        for (int w = 0; w < 4; ++w) { t2s += redb[w * 16 + tid]; t1s += redb[4 * 16 + w * 16 + tid]; }
+        sl2[C::WLEN + tid] = t2s; sl1[C::WLEN + tid] = t1s;
+    }
+}
+// Which whole-backward kernel the 16-channel blocks run: 0 = resblock_bwd_full_bf16_kernel (256 threads, two workgroups per CU), 1 = the
+// wave-specialised one (register staging), 2 = wave-specialised + LDS-DMA into RBFULL16D_NBUF tile buffers.  Measured (round 3, us per
+// 8192-sample launch): micro-bench on random data 0: 348-362, 1: 368-376, 2: 330-352 (2 or 3 buffers alike); in the engine 0: 272-275,
+// 2: 261-270.  dx is bit-identical in all three.  The two-role kernels are one workgroup per CU and end up bound by the same thing as the
+// plain one -- how fast a CU gets its 41 KB per item through its load path (an item's rows cost ~150 cycles of issue each, and one
+// workgroup per CU has a single item's bytes in flight) -- so 3 % did not buy the extra machinery a place as the default.
+#ifndef RBFULL16_SPECIALISED
+#define RBFULL16_SPECIALISED 0
+#endif
+#ifndef RBFULL16S_BPC
+#define RBFULL16S_BPC 1            // workgroups per CU of the specialised kernel
+#endif
 int resblock_bwd_full_grid(int n) {
+    if (RBFULL16_SPECIALISED) { const int w = n * RbFull16S::TPI; return w > 256 * RBFULL16S_BPC ? 256 * RBFULL16S_BPC : w; }
     int bpc = (int)((160 * 1024) / RbFull::LDS_BYTES);
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
     const int w = n * RbFull::TPI;
@@ -905,6 +1449,22 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
     if (grid < 1) return;
     RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
                  bank2_t, bank1_t, slab2, slab1, n};
+    if (RBFULL16_SPECIALISED) {
+        static std::once_flag attr_s;
+        // one workgroup per CU: request more LDS than the tiles need so that a second workgroup never lands on the same CU (RBFULL16S_BPC == 1)
+        constexpr size_t LDS_S = RBFULL16S_BPC == 1 ? (RbFull16S::LDS_BYTES > 84 * 1024 ? RbFull16S::LDS_BYTES : 84 * 1024) : RbFull16S::LDS_BYTES;
+        std::call_once(attr_s, [] { hipFuncSetAttribute((const void*)resblock_bwd_full16s_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_S); });
+        if (RBFULL16_SPECIALISED == 2) {
+            static std::once_flag attr_d;
+            constexpr size_t LDS_D = RBFULL16D_NBUF * RbFull16S::TILE_BYTES > RbFull16S::RED_BYTES ? RBFULL16D_NBUF * RbFull16S::TILE_BYTES : RbFull16S::RED_BYTES;
+            static_assert(LDS_D > 80 * 1024 && LDS_D <= 160 * 1024, "one workgroup per CU");
+            std::call_once(attr_d, [] { hipFuncSetAttribute((const void*)resblock_bwd_full16d_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_D); });
+            hipLaunchKernelGGL(resblock_bwd_full16d_bf16_kernel, dim3(grid), dim3(512), LDS_D, st, a);
+            return;
+        }
+        hipLaunchKernelGGL(resblock_bwd_full16s_bf16_kernel, dim3(grid), dim3(512), LDS_S, st, a);
+        return;
+    }
     hipLaunchKernelGGL(resblock_bwd_full_bf16_kernel, dim3(grid), dim3(RbFull::NT), RbFull::LDS_BYTES, st, a);
 }
 
