@@ -132,6 +132,7 @@ def fp32_record(hp, T, E, A, G, device, rank, iters=3):
         t_roll += time.perf_counter() - tr
         storage.compute_estimates(hp["gamma"], hp["lmbda"], hp["use_gae"], hp["normalize_adv"], agent.coll)
         summary = agent.optimize()
+        agent.draw_permutation_ahead()
     agent.engine.sync()
     dt = time.perf_counter() - t0
     agent.engine.close()
@@ -379,6 +380,7 @@ def main():
         phase["t_opt0"] = time.perf_counter(); phase["first_mb"] = None
         out = agent.optimize()
         phase["optimize_tail_s"] += time.perf_counter() - phase["last_enq"]        # last enqueue returned -> optimize() returned (log readback = the sync)
+        agent.draw_permutation_ahead()                         # as PPO.train does: the next update's first permutation is drawn behind the next rollout
         return out
 
     def fence():

@@ -249,3 +249,34 @@ def test_update_plan_positions_are_the_rows_places_in_the_global_minibatch():
             np.testing.assert_array_equal(local, shard_indices(chunks[k], EG, rank, world))
     for s in seen:
         assert np.all(s == 1)
+
+
+def test_permutation_drawn_ahead_is_the_in_place_permutation():
+    """Storage.draw_permutation_ahead (PPO.train: the next update's first torch.randperm, drawn by a helper thread behind the rollout):
+    the minibatch stream is bit-identical to the in-place draw -- same generator, same position, later epochs continue from it -- and a
+    permutation made stale by a re-seed (what every parity test does right before optimize()) is dropped, not used."""
+    import torch
+    from common.storage import Storage
+    st = Storage((3, 64, 64), 256, 16, 8, None)
+
+    def epochs(k, B=32, rec=False):
+        return [c.copy() for _ in range(k) for c in st.minibatch_index_stream(B, rec)]
+    torch.manual_seed(123)
+    want = epochs(3)
+    torch.manual_seed(123)
+    st.draw_permutation_ahead(16 * 8)
+    got = epochs(3)
+    assert len(got) == 12 and all(np.array_equal(a, b) for a, b in zip(want, got))
+    # stale: drawn, then the caller re-seeds -> the stream is the re-seeded one
+    torch.manual_seed(7)
+    st.draw_permutation_ahead(16 * 8)
+    st._perm_ahead._t.join()
+    torch.manual_seed(123)
+    got = epochs(3)
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    # wrong length (e.g. the policy's kind changed): dropped as well; recurrent streams take E-permutations
+    torch.manual_seed(5); want_r = epochs(1, 32, True)
+    torch.manual_seed(5); st.draw_permutation_ahead(8); got_r = epochs(1, 32, True)
+    assert all(np.array_equal(a, b) for a, b in zip(want_r, got_r))
+    torch.manual_seed(5); st.draw_permutation_ahead(999); st._perm_ahead._t.join(); torch.manual_seed(5)
+    assert all(np.array_equal(a, b) for a, b in zip(want_r, epochs(1, 32, True)))

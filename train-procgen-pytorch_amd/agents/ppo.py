@@ -268,6 +268,12 @@ class PPO(BaseAgent):
                 'Loss/atn_entropy': nan, 'Loss/atn_entropy2': nan, 'Loss/sparsity': nan,
                 'Loss/feature_sparsity': fs, 'Loss/total': float(np.mean(log[:, 4]))}
 
+    def draw_permutation_ahead(self):
+        """The first epoch's index permutation of the NEXT optimize() -- torch.randperm(T * E_global), or (E_global) for a recurrent policy
+        (common/storage.py:86-110) -- drawn by a helper thread from now on; same numbers as the in-place draw (Storage.draw_permutation_ahead)."""
+        n = self.n_envs_global if self.policy.is_recurrent() else self.n_steps * self.n_envs_global
+        self.storage.draw_permutation_ahead(n)
+
     # ------------------------------------------------------------------ rollout + train
     def _collect(self, env, engine, storage, obs, hidden_state, done):
         if len(getattr(env, "env_groups", ())) > 1 and not self.policy.is_recurrent() and self.n_envs % len(env.env_groups) == 0:
@@ -373,6 +379,7 @@ class PPO(BaseAgent):
             self.logger.feed(rew_batch, done_batch, true_average_reward, rew_batch_v, done_batch_v, true_average_reward_v)
             self.optimizer, lr = self.adjust_lr(self.optimizer, self.learning_rate, self.t, num_timesteps)
             self.logger.dump(summary, lr)
+            self.draw_permutation_ahead()                    # the next update's first permutation, behind the next rollout
             if checkpoint_cnt < len(checkpoints) and self.t > checkpoints[checkpoint_cnt]:
                 if self.coll.rank == 0:
                     print("Saving model.")

@@ -29,6 +29,30 @@ def _randperm_serial(n):
         torch.set_num_threads(k)
 
 
+class _PermutationAhead:
+    """The first epoch's torch.randperm(n) of the NEXT update, drawn by a helper thread while the rollout runs (PPO.train starts it at
+    the end of an iteration).  At the head of optimize() the GPU is idle behind that draw: 0.6 ms for n = 65 536, 8 ms for the 524 288
+    indices of an 8-GPU run (9 % of an iteration).  The numbers are the ones an in-place draw would give -- same generator, same
+    position -- provided nothing touched the generator in between; that is checked (state after the draw == state at use), and a
+    stale permutation (a caller re-seeded, as the tests do) is dropped in favour of a fresh draw."""
+
+    def __init__(self, n):
+        import threading
+        self.n, self.perm, self.state_after = n, None, None
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _run(self):
+        self.perm = _randperm_serial(self.n)
+        self.state_after = torch.get_rng_state()
+
+    def take(self, n):
+        self._t.join()
+        if n == self.n and self.perm is not None and torch.equal(self.state_after, torch.get_rng_state()):
+            return self.perm
+        return None
+
+
 class Storage:
     def __init__(self, obs_shape, hidden_state_size, num_steps, num_envs, device, continuous_actions=False,
                  act_shape=None):
@@ -43,6 +67,7 @@ class Storage:
         self.num_envs = num_envs
         self.device = device
         self.engine = None
+        self._perm_ahead = None
         self.arch = "impala" if len(self.obs_shape) == 3 else "mlp"
         # host mirrors of reward / done: what Logger and fetch_log_data read (pinned once an engine is attached)
         self._rew = np.zeros((num_steps, num_envs), np.float32)
@@ -149,16 +174,27 @@ class Storage:
         T = self.num_steps
         N = T * E
         B = N if mini_batch_size is None else mini_batch_size
+        ahead, self._perm_ahead = self._perm_ahead, None
+        draw = lambda n: (ahead.take(n) if ahead is not None else None)
         if not recurrent:
-            perm = _randperm_serial(N)
+            perm = draw(N)
+            if perm is None:
+                perm = _randperm_serial(N)
             for k in range(N // B):
                 yield perm[k * B:(k + 1) * B].astype(np.int64)
         else:
             per = E // (N // B)
-            perm = _randperm_serial(E)
+            perm = draw(E)
+            if perm is None:
+                perm = _randperm_serial(E)
             for s in range(0, E, per):
                 envs = perm[s:s + per].astype(np.int64)
                 yield (np.arange(T, dtype=np.int64)[:, None] * E + envs[None, :]).reshape(-1)
+
+    def draw_permutation_ahead(self, n):
+        """Start drawing the next update's first torch.randperm(n) now (see _PermutationAhead): call when nothing else will use torch's
+        CPU generator until that update -- PPO.train does, right after an iteration's logging."""
+        self._perm_ahead = _PermutationAhead(int(n))
 
     # ------------------------------------------------------------------ reference API: reads (compat, not the hot path)
     def _field(self, f):
