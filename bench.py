@@ -100,45 +100,23 @@ def cpu_baseline(hp, E, A, t_sample, threads):
                        f"(forward, backward, clip, Adam) {t_epoch:.1f} s, counted {hp['epoch']}x")
 
 
-def fp32_record(hp, T, E, A, G, device, rank, iters=3):
+def fp32_record(args, iters=3):
     """The same iteration in the fp32 PARITY mode (the mode the 1e-4 loss / return parity with the reference is stated and tested in;
     exact-fp32 matrix instructions), `iters` timed iterations after one warm-up, product collector included: a driver-run number for it
-    beside the bf16 headline."""
-    from agents.ppo import PPO
-    from common.env.vec_envs import EnvGroups, SyntheticTape
-    from common.model import ImpalaModel
-    from common.policy import CategoricalPolicy
-    from common.storage import Storage
-    torch.manual_seed(6033)
-    model = ImpalaModel(in_channels=3)
-    policy = CategoricalPolicy(model, False, A)
-    policy.device = device
-    storage = Storage((3, 64, 64), model.output_dim, T, E, device)
-
-    class _Log:
-        episode_reward_buffer = [0.0]
-        logdir = "/tmp"
-    agent = PPO(None, policy, _Log(), storage, device, 1, seed=rank, precision="fp32", **hp)
-    ng = E // G
-    env = EnvGroups([SyntheticTape(ng, A, seed=1000 * rank + g, length=T) for g in range(G)]) if G > 1 else SyntheticTape(E, A, seed=1000 * rank, length=T)
-    roll = [env.reset(), np.zeros((E, storage.hidden_state_size), np.float32), np.zeros(E, np.float32)]
-    t_roll = 0.0
-    for it in range(iters + 1):
-        if it == 1:
-            agent.engine.sync(); t_roll = 0.0; t0 = time.perf_counter()
-        agent._iter = it + 1
-        tr = time.perf_counter()
-        roll = list(agent._collect(env, agent.engine, storage, *roll))
-        t_roll += time.perf_counter() - tr
-        storage.compute_estimates(hp["gamma"], hp["lmbda"], hp["use_gae"], hp["normalize_adv"], agent.coll)
-        summary = agent.optimize()
-        agent.draw_permutation_ahead()
-    agent.engine.sync()
-    dt = time.perf_counter() - t0
-    agent.engine.close()
-    return {"value": T * E * iters / dt, "unit": "env steps/s", "ms_per_step": dt / iters * 1e3, "steps": iters, "rollout_ms": t_roll / iters * 1e3,
-            "dtype": "f32", "loss_total": summary["Loss/total"],
-            "whole_step_roofline_mfma_frac": T * E * iters / dt * 601.78e6 / (MFMA_F32_PEAK_TF * 1e12)}
+    beside the bf16 headline.  Run as a CHILD process of this script (a second engine in this process lands its env-group streams on
+    hardware queues the first one already occupies and its rollout serialises: 218 instead of 88 ms)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--precision", "fp32", "--steps", str(iters), "--warmup", "1", "--no-cpu-baseline",
+           "--no-fp32-record", "--param_name", args.param_name, "--n-actions", str(args.n_actions), "--rollout-groups", str(args.rollout_groups)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                                   # the headline line must not depend on this leg
+        return {"error": f"{type(e).__name__}: {e}"}
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"],
+            "rollout_ms": d["phase_ms_per_step"]["rollout"], "update_ms": d["phase_ms_per_step"]["update"], "loss_total": d["loss_total"],
+            "whole_step_roofline_mfma_frac": d["whole_step_roofline"]["mfma_frac"],
+            "dominant_kernel": None if d["roofline"] is None else {k: d["roofline"][k] for k in ("kernel", "avg_launch_ms", "mfma_TFps", "mfma_frac", "hbm_GBps")}}
 
 
 def rocprof_name(cls, precision):
@@ -461,7 +439,7 @@ def main():
                "loss_total": summary["Loss/total"]}
         if world == 1 and args.precision == "bf16" and not args.no_fp32_record and not args.engine_only and args.rank_share == 1:
             eng.close()
-            out["fp32"] = fp32_record(hp, T, E, A, G, device, rank)
+            out["fp32"] = fp32_record(args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hp, E, A, args.cpu_sample, args.cpu_threads or host_cores())
         print(json.dumps(out))
