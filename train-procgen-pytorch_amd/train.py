@@ -19,7 +19,10 @@ if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:       # before anything initi
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
 # the pipelined rollout runs up to 4 env-group streams beside the main stream: with the runtime's default of 4 hardware queues two
 # of them share a queue and serialise (measured: 4 groups 194 us per step with 4 queues, 134 us with 8)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if "--no-use_valid_env" in sys.argv else "16")
+# (validation rollouts -- on by default -- run on a second engine with env-group streams of its own: with 8 queues two of ITS streams share
+#  a queue with the training engine's and its rollout takes 45.7 instead of 29 ms, scratch/valid_rollout_time.py; without the second
+#  engine 16 queues cost the update phase 0.6 %)
 
 import argparse
 import random
