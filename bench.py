@@ -157,7 +157,7 @@ def pmc_traffic(cls, precision):
     gfx950 correction + WRITE_SIZE; profiles/r0N_pmc_<precision>.json, collected on 8192-sample launches by
     scratch/pmc_workload.py).  None when no committed counter summary matches."""
     keys = rocprof_name(cls, precision)
-    for rnd in ("r02", "r01"):                      # the newest committed counter summary that has this kernel
+    for rnd in ("r03", "r02", "r01"):               # the newest committed counter summary that has this kernel
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{precision}.json")))
         except Exception:

@@ -1,6 +1,6 @@
 import csv, glob, sys
 d = sys.argv[1]
-rows = list(csv.DictReader(open(glob.glob(d + "/runc*kernel_stats.csv")[0])))
+rows = list(csv.DictReader(open((glob.glob(d + "/runc*kernel_stats.csv") + glob.glob(d + "/r03_run1_bf16_kernel_stats.csv"))[0])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 print("total kernel ms per iter", tot / n / 1e6)

@@ -1,0 +1,27 @@
+"""Rollout time of the training engine vs the validation twin (two engines in one process): ms per T = 256 rollout at E = 256, bf16."""
+import os, sys, time, numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", sys.argv[1] if len(sys.argv) > 1 else "8")
+sys.path[:0] = [".", "train-procgen-pytorch_amd"]
+import torch, yaml
+from agents.ppo import PPO
+from common.env.vec_envs import EnvGroups, SyntheticTape
+from common.model import ImpalaModel
+from common.policy import CategoricalPolicy
+from common.storage import Storage
+hp = yaml.safe_load(open("train-procgen-pytorch_amd/hyperparams/procgen/config.yml"))["hard-500"]
+T, E, A, G = hp["n_steps"], hp["n_envs"], 9, 4
+dev = torch.device("cuda", 0)
+torch.manual_seed(1)
+policy = CategoricalPolicy(ImpalaModel(3), False, A); policy.device = dev
+st, stv = Storage((3, 64, 64), 256, T, E, dev), Storage((3, 64, 64), 256, T, E, dev)
+class L: episode_reward_buffer = [0.0]; logdir = "/tmp"
+agent = PPO(None, policy, L(), st, dev, 1, storage_valid=stv, precision="bf16", **hp)
+mk = lambda s: EnvGroups([SyntheticTape(E // G, A, seed=s + g, length=T) for g in range(G)])
+env, envv = mk(0), mk(100)
+r = [env.reset(), np.zeros((E, 256), np.float32), np.zeros(E, np.float32)]
+rv = [envv.reset(), np.zeros((E, 256), np.float32), np.zeros(E, np.float32)]
+for it in range(4):
+    t0 = time.perf_counter(); r = list(agent._collect(env, agent.engine, st, *r)); t1 = time.perf_counter()
+    agent.engine_valid.copy_params_from(agent.engine)
+    rv = list(agent._collect(envv, agent.engine_valid, stv, *rv)); t2 = time.perf_counter()
+    print(f"queues {os.environ['GPU_MAX_HW_QUEUES']} iteration {it}: train rollout {1e3 * (t1 - t0):.1f} ms, validation rollout {1e3 * (t2 - t1):.1f} ms")
