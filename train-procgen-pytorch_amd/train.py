@@ -172,7 +172,10 @@ def make_env(env_name, n_envs, seed, A, args, hp, is_valid=False):
     """get_env_constructor(env_name)(args, hp, is_valid) (common/env/env_constructor.py:13-31) for the envs of the PPO path.  With
     --rollout_groups G > 1 (and a non-recurrent policy) the n_envs environments are G independent sub-envs behind one VecEnv
     (EnvGroups): same protocol outwards, and the agent pipelines the groups.  Procgen groups share ONE running return variance, so
-    reward normalisation stays a single statistic over all envs (procgen_wrappers.py:316-355)."""
+    reward normalisation stays a single statistic over all envs (procgen_wrappers.py:316-355) -- but it is UPDATED per group step:
+    group g's rewards of step t are scaled by a variance that already holds groups < g of step t and not yet groups > g, where the
+    reference's VecNormalize folds all n_envs returns in before scaling any.  The statistic converges to the same value; individual
+    scaled rewards differ in the last digits early on.  `--rollout_groups 1` gives the reference's exact scaling (and its serial step)."""
     G = int(getattr(args, "rollout_groups", 1))
     if G > 4:
         raise ValueError(f"--rollout_groups {G}: the engine pipelines at most 4 env groups (mi_rollout_groups; more busy streams than that serialise)")
