@@ -120,6 +120,52 @@ def test_pipelined_collect_equals_serial_collect(precision):
         assert np.array_equal(res[0][k], res[1][k]), k
 
 
+def test_joint_training_and_validation_rollouts():
+    """PPO._collect_lanes with two lanes (training engine + validation twin, what PPO.train runs when both envs carry env groups): the
+    training lane leaves its ring exactly as the solo pipelined collector does (same kernels, same Philox counters), the validation lane
+    -- its own engine, its own Philox stream -- stores its env's frames / rewards / dones and policy outputs that the twin's stateless
+    forward reproduces on the stored frames (log-prob of the stored action, value)."""
+    from agents.ppo import PPO
+    from common.env.vec_envs import EnvGroups, SyntheticFrames
+    from common.model import ImpalaModel
+    from common.policy import CategoricalPolicy
+    from common.storage import Storage
+    from mi355 import engine as M
+    T, E, G = 5, 16, 2
+    dev = torch.device("cuda", 0)
+
+    def build():
+        torch.manual_seed(3)
+        policy = CategoricalPolicy(ImpalaModel(3), False, 15)
+        with torch.no_grad():
+            policy.fc_policy.weight.mul_(150.0)
+        st, stv = Storage((3, 64, 64), 256, T, E, dev), Storage((3, 64, 64), 256, T, E, dev)
+        agent = PPO(None, policy, _Log(), st, dev, 1, storage_valid=stv, n_steps=T, n_envs=E, epoch=1, n_minibatch=1, mini_batch_size=16, precision="bf16")
+        agent._iter = 1
+        agent.engine_valid.copy_params_from(agent.engine)
+        mk = lambda s: EnvGroups([SyntheticFrames(E // G, 15, seed=s + g) for g in range(G)])
+        return agent, st, stv, mk(0), mk(50)
+
+    z = lambda: (np.zeros((E, 256), np.float32), np.zeros(E, np.float32))
+    a1, st1, stv1, env1, envv1 = build()
+    (o, h, d), (ov, hv, dv) = a1._collect_lanes([(env1, a1.engine, st1, env1.reset(), *z()), (envv1, a1.engine_valid, stv1, envv1.reset(), *z())])
+    a2, st2, _, env2, _ = build()
+    o2, h2, d2 = a2._collect(env2, a2.engine, st2, env2.reset(), *z())
+    for f in (M.F_ACT, M.F_LOGP, M.F_VALUE, M.F_REW, M.F_DONE):
+        assert np.array_equal(a1.engine.read_field(f), a2.engine.read_field(f)), f
+    assert all(np.array_equal(a1.engine.get_obs(t), a2.engine.get_obs(t)) for t in range(T + 1)) and np.array_equal(o, o2) and np.array_equal(d, d2)
+    ev = a1.engine_valid
+    act, logp, val = ev.read_field(M.F_ACT), ev.read_field(M.F_LOGP), ev.read_field(M.F_VALUE)
+    assert not np.array_equal(act, a1.engine.read_field(M.F_ACT)) and len(np.unique(act)) > 3
+    for t in range(T):
+        lp_all, v = ev.forward(ev.get_obs(t))
+        np.testing.assert_allclose(lp_all[np.arange(E), act[t].astype(int)], logp[t], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(v, val[t], rtol=0, atol=2e-6)
+    assert np.array_equal(ev.get_obs(T), ov) and len(stv1.info_batch) == T and np.array_equal(stv1._done[T - 1], dv)
+    rb, db, _ = stv1.fetch_log_data()
+    assert rb.shape == (T, E) and np.array_equal(db, ev.read_field(M.F_DONE))
+
+
 def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     """torch.save({'model_state_dict','optimizer_state_dict'}) (agents/ppo.py:271-276) loads into plain torch
     objects with the reference's key names, and back into a fresh agent bit-exactly (train.py:257-263)."""

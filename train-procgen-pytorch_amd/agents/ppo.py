@@ -54,6 +54,7 @@ class PPO(BaseAgent):
         self.adjust_lr = adjust_lr_grok if increasing_lr else adjust_lr
         self.seed = int(kwargs.get("seed", 0))
         self.merge_accumulation = bool(kwargs.get("merge_accumulation", True))      # (new) see optimize()
+        self.joint_rollouts = bool(kwargs.get("joint_rollouts", True))              # (new) training + validation rollout in one host loop (train())
         # train.py --detect_nan (reference: autograd anomaly mode + a NaN hook on every module's output, train.py:123-124,234-250):
         # here the policy outputs of every rollout step, every minibatch's loss record and every gradient norm are checked
         self.detect_nan = bool(kwargs.get("detect_nan", False))
@@ -276,7 +277,7 @@ class PPO(BaseAgent):
 
     # ------------------------------------------------------------------ rollout + train
     def _collect(self, env, engine, storage, obs, hidden_state, done):
-        if len(getattr(env, "env_groups", ())) > 1 and not self.policy.is_recurrent() and self.n_envs % len(env.env_groups) == 0:
+        if self._can_pipeline(env):
             return self._collect_pipelined(env, engine, storage, obs, hidden_state, done)
         for _ in range(self.n_steps):
             t = storage.step
@@ -298,51 +299,75 @@ class PPO(BaseAgent):
         and only otherwise through a copy into a pinned staging buffer (786 KB per group step at E = 256: tens of microseconds of one
         core inside a ~105 us dependency chain); results are written into this call's arrays through raw addresses; a step's infos
         stay per-group objects (StepInfo.join), nothing is walked entry by entry."""
+        return self._collect_lanes([(env, engine, storage, obs, hidden_state, done)])[0]
+
+    def _collect_lanes(self, lanes):
+        """Several rollouts side by side -- `lanes` = [(env with .env_groups, engine, storage, obs, hidden_state, done), ...], each on its own
+        engine -- in ONE host loop: every (lane, group) is an independent chain.  One lane is the pipelined collector of PPO.train; two
+        lanes are the training and the validation rollout of an iteration (agents/ppo.py:225-252 runs them one after the other on the same
+        policy; neither depends on the other): both are latency chains that leave the GPU mostly idle, so interleaved they take little
+        longer than one alone."""
         from common.env.vec_envs import StepInfo
-        groups = env.env_groups
-        G, E, T = len(groups), self.n_envs, self.n_steps
-        ng = E // G
-        key = id(engine)
-        arch = self.policy.arch
-        if getattr(engine, "n_groups", 1) != G:
-            engine.rollout_groups(G)
-        st = self._gstage.setdefault(key, [[engine.pinned((ng,) + self._obs_stage_shape(arch, self.policy.embedder),
-                                                          self._obs_dtype(arch)) for _ in range(2)] for _ in range(G)])
-        obs_g = [obs[g * ng:(g + 1) * ng] for g in range(G)]
-        rew = np.zeros(E, np.float32); dn = np.zeros(E, np.float32)
-        act = np.zeros(E, np.int64); logp = np.zeros(E, np.float32); val = np.zeros(E, np.float32)
-        pa, pl, pv = (a.__array_interface__['data'][0] for a in (act, logp, val))
-        sls = [slice(g * ng, (g + 1) * ng) for g in range(G)]
-        infos = [None] * G
-        seed = self.seed * 1000003 + self._iter
+        T, arch = self.n_steps, self.policy.arch
         want_dtype = self._obs_dtype(arch)
-        wait, submit, ready = engine.rollout_wait_into, engine.rollout_submit, engine.dma_ready
+
+        class Lane:
+            pass
+        Ls = []
+        for k, (env, engine, storage, obs, hidden_state, done) in enumerate(lanes):
+            L = Lane()
+            L.groups, L.engine, L.storage, L.hidden = env.env_groups, engine, storage, hidden_state
+            L.G, E = len(L.groups), self.n_envs
+            ng = E // L.G
+            if getattr(engine, "n_groups", 1) != L.G:
+                engine.rollout_groups(L.G)
+            L.st = self._gstage.setdefault((id(engine), L.G), [[engine.pinned((ng,) + self._obs_stage_shape(arch, self.policy.embedder), want_dtype)
+                                                                for _ in range(2)] for _ in range(L.G)])
+            L.obs_g = [obs[g * ng:(g + 1) * ng] for g in range(L.G)]
+            L.rew = np.zeros(E, np.float32); L.dn = np.zeros(E, np.float32)
+            L.act = np.zeros(E, np.int64); L.logp = np.zeros(E, np.float32); L.val = np.zeros(E, np.float32)
+            L.pa, L.pl, L.pv = (a.__array_interface__['data'][0] for a in (L.act, L.logp, L.val))
+            L.sls = [slice(g * ng, (g + 1) * ng) for g in range(L.G)]
+            L.infos = [None] * L.G
+            # the validation lane draws from its own Philox stream (the reference's two rollouts share torch's generator, not its numbers)
+            L.seed = self.seed * 1000003 + self._iter + (k << 40)
+            L.wait, L.submit, L.ready = engine.rollout_wait_into, engine.rollout_submit, engine.dma_ready
+            Ls.append(L)
         for t in range(T + 1):
-            for g in range(G):
-                sl = sls[g]
-                if t:
-                    wait(g, pa + 8 * sl.start, pl + 4 * sl.start, pv + 4 * sl.start)
-                    o, r, d, infos[g] = groups[g].step(act[sl])
-                    obs_g[g] = o
-                    rew[sl] = r; dn[sl] = d
-                else:
-                    o = obs_g[g]
-                # upload in place when the env's array already is what the ring stores, else convert / copy into the pinned stage
-                if t and isinstance(o, np.ndarray) and o.dtype == want_dtype and o.flags.c_contiguous and (arch != "impala" or o.shape[-1] == 3) and ready(o):
-                    buf = o
-                else:
-                    buf = st[g][t & 1]
-                    buf[...] = as_device_obs(o, arch)
-                submit(t, g, buf, rew[sl] if t else None, dn[sl] if t else None, seed=seed)
+            for g in range(max(L.G for L in Ls)):
+                for L in Ls:
+                    if g >= L.G:
+                        continue
+                    sl = L.sls[g]
+                    if t:
+                        L.wait(g, L.pa + 8 * sl.start, L.pl + 4 * sl.start, L.pv + 4 * sl.start)
+                        o, r, d, L.infos[g] = L.groups[g].step(L.act[sl])
+                        L.obs_g[g] = o
+                        L.rew[sl] = r; L.dn[sl] = d
+                    else:
+                        o = L.obs_g[g]
+                    # upload in place when the env's array already is what the ring stores, else convert / copy into the pinned stage
+                    if t and isinstance(o, np.ndarray) and o.dtype == want_dtype and o.flags.c_contiguous and (arch != "impala" or o.shape[-1] == 3) and L.ready(o):
+                        buf = o
+                    else:
+                        buf = L.st[g][t & 1]
+                        buf[...] = as_device_obs(o, arch)
+                    L.submit(t, g, buf, L.rew[sl] if t else None, L.dn[sl] if t else None, seed=L.seed)
             if t:
-                if self.detect_nan and not (np.isfinite(val).all() and np.isfinite(logp).all()):
-                    raise RuntimeError(f"Found NaN / Inf in the policy outputs of rollout step {t - 1}")
-                storage.note_stored(rew, dn, StepInfo.join(infos))       # (hidden-state mirror: all zeros for a non-recurrent policy, left as is)
-        for g in range(G):
-            wait(g, pa + 8 * sls[g].start, pl + 4 * sls[g].start, pv + 4 * sls[g].start)
-        obs = np.concatenate(obs_g)
-        storage._hidden[T] = hidden_state                    # store_last: value[T] and the frames are already in the device ring
-        return obs, hidden_state, dn.copy()
+                for L in Ls:
+                    if self.detect_nan and not (np.isfinite(L.val).all() and np.isfinite(L.logp).all()):
+                        raise RuntimeError(f"Found NaN / Inf in the policy outputs of rollout step {t - 1}")
+                    L.storage.note_stored(L.rew, L.dn, StepInfo.join(L.infos))       # (hidden-state mirror: all zeros for a non-recurrent policy, left as is)
+        out = []
+        for L in Ls:
+            for g in range(L.G):
+                L.wait(g, L.pa + 8 * L.sls[g].start, L.pl + 4 * L.sls[g].start, L.pv + 4 * L.sls[g].start)
+            L.storage._hidden[T] = L.hidden                  # store_last: value[T] and the frames are already in the device ring
+            out.append((np.concatenate(L.obs_g), L.hidden, L.dn.copy()))
+        return out
+
+    def _can_pipeline(self, env):
+        return len(getattr(env, "env_groups", ())) > 1 and not self.policy.is_recurrent() and self.n_envs % len(env.env_groups) == 0
 
     def train(self, num_timesteps):
         self.total_timesteps = num_timesteps
@@ -360,13 +385,25 @@ class PPO(BaseAgent):
 
         while self.t < num_timesteps:
             self._iter += 1
-            obs, hidden_state, done = self._collect(self.env, self.engine, self.storage, obs, hidden_state, done)
-            self.storage.compute_estimates(self.gamma, self.lmbda, self.use_gae, self.normalize_adv, self.coll)
             if self.env_valid is not None:
-                self.engine_valid.copy_params_from(self.engine)          # device to device (mi_copy_params)
-                obs_v, hidden_state_v, done_v = self._collect(self.env_valid, self.engine_valid, self.storage_valid,
-                                                              obs_v, hidden_state_v, done_v)
+                self.engine_valid.copy_params_from(self.engine)          # device to device (mi_copy_params): both rollouts run the current policy
+            if (self.env_valid is not None and self.joint_rollouts and self._can_pipeline(self.env) and self._can_pipeline(self.env_valid)
+                    and len(self.env.env_groups) + len(self.env_valid.env_groups) <= 4):     # (more than four busy streams serialise: 8 chains 86-94 ms)
+                # training and validation rollout as chains of ONE host loop (neither depends on the other; ppo.py:225-252 runs them in turn):
+                # at E = 256 with 2 + 2 env groups 49.5 ms for both, against 28.4 + 28.5 ms one after the other with 4 groups each
+                # (scratch/valid_rollout_time.py)
+                (obs, hidden_state, done), (obs_v, hidden_state_v, done_v) = self._collect_lanes(
+                    [(self.env, self.engine, self.storage, obs, hidden_state, done),
+                     (self.env_valid, self.engine_valid, self.storage_valid, obs_v, hidden_state_v, done_v)])
+                self.storage.compute_estimates(self.gamma, self.lmbda, self.use_gae, self.normalize_adv, self.coll)
                 self.storage_valid.compute_estimates(self.gamma, self.lmbda, self.use_gae, self.normalize_adv)
+            else:
+                obs, hidden_state, done = self._collect(self.env, self.engine, self.storage, obs, hidden_state, done)
+                self.storage.compute_estimates(self.gamma, self.lmbda, self.use_gae, self.normalize_adv, self.coll)
+                if self.env_valid is not None:
+                    obs_v, hidden_state_v, done_v = self._collect(self.env_valid, self.engine_valid, self.storage_valid,
+                                                                  obs_v, hidden_state_v, done_v)
+                    self.storage_valid.compute_estimates(self.gamma, self.lmbda, self.use_gae, self.normalize_adv)
             summary = self.optimize()
             self.t += steps_per_iter
             rew_batch, done_batch, true_average_reward = self.storage.fetch_log_data()

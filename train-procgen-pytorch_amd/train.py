@@ -112,7 +112,7 @@ def add_training_args(p):
     p.add_argument('--precision', type=str, default=None, choices=['fp32', 'bf16'],
                    help="IMPALA activation storage / matrix-core type: fp32 = parity mode (default), bf16 = BASELINE config 3 (what bench.py measures)")
     p.add_argument('--rollout_groups', type=int, default=0,
-                   help="env groups of the pipelined rollout (one group's frame upload + forward beside the host's env.step of another); 0 = auto (4 from 128 envs per rank, else 2); 1 = the reference's serial step")
+                   help="env groups of the pipelined rollout (one group's frame upload + forward beside the host's env.step of another); 0 = auto (from 128 envs per rank: 4, or 2 + 2 when a validation env runs beside the training env; else 2); 1 = the reference's serial step")
     p.add_argument('--x_entropy_coef', type=float, default=None)
     return p
 
@@ -180,7 +180,8 @@ def make_env(env_name, n_envs, seed, A, args, hp, is_valid=False):
     if G > 4:
         raise ValueError(f"--rollout_groups {G}: the engine pipelines at most 4 env groups (mi_rollout_groups; more busy streams than that serialise)")
     if G <= 0:
-        G = 4 if n_envs >= 128 and n_envs % 8 == 0 else 2
+        # auto: 4 chains keep the GPU's stream slots busy; with a validation env the agent runs both rollouts as lanes of one loop, 2 + 2
+        G = (2 if getattr(args, "use_valid_env", False) else 4) if n_envs >= 128 and n_envs % 8 == 0 else 2
     if G == 1 or hp.get("recurrent", False) or n_envs % G or (n_envs // G) % 2 or env_name.startswith("cartpole"):
         return _one_env(env_name, n_envs, seed, A, args, hp, is_valid)
     rms = None
