@@ -1427,6 +1427,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16d_bf16_kernel(RbFul
 // 2: 261-270.  dx is bit-identical in all three.  The two-role kernels are one workgroup per CU and end up bound by the same thing as the
 // plain one -- how fast a CU gets its 41 KB per item through its load path (an item's rows cost ~150 cycles of issue each, and one
 // workgroup per CU has a single item's bytes in flight) -- so 3 % did not buy the extra machinery a place as the default.
+// (Also tried on variant 2: two more waves, 640 threads, that only issue the row DMAs and wait for them -- the kernel then has to fit
+//  168 registers, spills 28-43 whatever the conv group size, and runs 560 us; issuing the rows from a run-time loop instead of the
+//  unrolled one: 415 against 335.)
 #ifndef RBFULL16_SPECIALISED
 #define RBFULL16_SPECIALISED 0
 #endif
