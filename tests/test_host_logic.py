@@ -280,3 +280,35 @@ def test_permutation_drawn_ahead_is_the_in_place_permutation():
     assert all(np.array_equal(a, b) for a, b in zip(want_r, got_r))
     torch.manual_seed(5); st.draw_permutation_ahead(999); st._perm_ahead._t.join(); torch.manual_seed(5)
     assert all(np.array_equal(a, b) for a, b in zip(want_r, epochs(1, 32, True)))
+
+
+def test_update_plan_c4_shape_eight_ranks_in_process():
+    """BASELINE config 4's update schedule (E = 2048 over 8 ranks, T = 256: N = 524 288, global minibatch 8192, 8 accumulated minibatches per
+    optimizer step) as mi355/dist.py::update_plan emits it for each of the 8 ranks -- pure index logic, all ranks in this process:
+    the same operation sequence on every rank (what keeps their collectives matched), 8 optimizer steps per epoch, every pass within
+    max_batch and its segments adding up, and over the ranks every global sample visited exactly once per epoch, by the rank that
+    owns its env."""
+    import torch
+    from mi355.dist import update_plan, env_range
+    T, E, R, B = 256, 2048, 8, 8192
+    N = T * E
+    torch.manual_seed(0)
+    perm = torch.randperm(N).numpy()
+    chunks = [perm[k * B:(k + 1) * B].astype(np.int64) for k in range(N // B)]
+    max_batch = int(B * 1.07) + 64
+    seqs, seen = [], np.zeros(N, np.int32)
+    for r in range(R):
+        ops = list(update_plan(iter(chunks), r, R, E, (N // 8) / B, True, False, max_batch))
+        seqs.append([(o[0], len(o[2]) if o[0] == "minibatch" else None, o[3] if o[0] == "minibatch" else None) for o in ops])
+        e0, e1 = env_range(E, r, R)
+        for o in ops:
+            if o[0] != "minibatch":
+                continue
+            local, seg = o[1], o[2]
+            assert len(local) == sum(seg) <= max_batch and o[3] == B
+            t, e = local // (e1 - e0), local % (e1 - e0)
+            seen[t * E + e0 + e] += 1
+    assert all(s == seqs[0] for s in seqs)                       # rank-uniform schedule
+    kinds = [k for k, _, _ in seqs[0]]
+    assert kinds.count("step") == 8 and kinds.count("minibatch") == 8 and kinds[-1] == "log" and seqs[0][0] == ("minibatch", 8, B)
+    assert (seen == 1).all()
