@@ -125,7 +125,7 @@ def rocprof_name(cls, precision):
     kind, cin, cout, hw = parts[1], *[int(x) for x in parts[2:5]]
     if parts[0] == "resblock":                        # fused residual block (bf16 mode): RbCfg<C, HW, TH, NIMG>, BWD
         if kind == "dgrad" and cin == 16:             # 16-channel blocks: data + weight gradients in one kernel
-            return ["resblock_bwd_full_bf16_kernel"]
+            return ["resblock_bwd_full16d_bf16_kernel"]      # (round 3: two roles + LDS-DMA tiles; rounds 1-2: resblock_bwd_full_bf16_kernel)
         if kind == "dgrad" and hw == 16:              # 32-channel blocks @16x16: likewise (wave-specialised 512-thread workgroups)
             return ["resblock_bwd_full32"]
         if kind == "dgrad" and hw == 8:
@@ -173,7 +173,7 @@ def pmc_traffic(cls, precision):
 # Tensor passes the FUSED bf16 kernels really move, as a fraction of the SURVEY 8(d) layer-boundary bytes they are priced at
 # (the model charges every conv / pool boundary; fusion keeps those tensors in LDS).  Used for the `own_*` fields only.
 OWN_TRAFFIC = {
-    "resblock_dgrad": 4.0 / 7.0,          # whole backward of a residual block: dy, a, x in; dx out   vs 2 x 3p + p
+    "resblock_dgrad": 4.0 / 7.0,          # whole backward of a residual block: dy, a, x in; dx out   vs 2 x 3p + p   (halo rows re-read on top: PMC)
     "resblock_fwd": 5.0 / 10.0,           # res1 + res2: x in; a1, y1, a2, y2 out                    vs 2 x (2 x 2p + p)
     "conv_fwd_3_16_64": 61440.0 / 307200.0,           # frames in, pooled map + arg-max out             vs I + 2X + p
     "conv_wgrad_3_16_64": 61440.0 / 438272.0,         # frames, pooled gradient + arg-max in            vs I + 3X + p

@@ -916,13 +916,22 @@ struct RbFull16ST {
     static constexpr size_t LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
     static_assert(NMT2 % 4 == 0 && TH % 4 == 0, "whole tiles / rows per wave");
 };
-#ifndef RBFULL16S_TH
-#define RBFULL16S_TH 8
+#ifndef RBFULL16_SPECIALISED
+#define RBFULL16_SPECIALISED 2     // (see the end of this section)
 #endif
+#ifndef RBFULL16S_TH
+#define RBFULL16S_TH (RBFULL16_SPECIALISED == 2 ? 16 : 8)      // tile rows of the two-role kernels: 16 with the LDS-DMA fill (two items per image: rows
+#endif                                                         // re-read for the halo 1.17x instead of 1.33x; 2 x 60 KB of DMA-filled tiles + 19 KB)
 #ifndef RBFULL16S_CG
 #define RBFULL16S_CG 2
 #endif
 using RbFull16S = RbFull16ST<RBFULL16S_TH>;
+#ifdef RBF_TIMING
+#define S16_TCK(k) do { if ((tid & 255) == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
+#else
+#define S16_TCK(k) do { } while (0)
+#endif
+#if RBFULL16_SPECIALISED == 1
 
 __global__ __launch_bounds__(512, 2) void resblock_bwd_full16s_bf16_kernel(RbFullArgs a) {
     using C = RbFull16S;
@@ -937,9 +946,6 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16s_bf16_kernel(RbFul
     const int rw = wv & 3;
 #ifdef RBF_TIMING
     long long tacc_[4] = {0, 0, 0, 0}, tlast_ = clock64();
-#define S16_TCK(k) do { if ((tid & 255) == 0) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
-#else
-#define S16_TCK(k) do { } while (0)
 #endif
     for (int e = tid; e < (C::X_ELEMS + 3 * C::Y_ELEMS) / 8; e += C::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};   // column halos stay zero
     // ONE register array for both roles (two sets: the kernel's allocation is the union of what its waves may keep live).
@@ -1155,12 +1161,13 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16s_bf16_kernel(RbFul
         sl2[C::WLEN + tid] = t2s; sl1[C::WLEN + tid] = t1s;
     }
 }
-// ---- the same two roles with the tiles filled by LDS-DMA into TWO tile buffers (RBFULL16_SPECIALISED == 2).
+#endif      // RBFULL16_SPECIALISED == 1
+// ---- the same two roles with the tiles filled by LDS-DMA into TWO tile buffers (RBFULL16_SPECIALISED == 2, the default).
 // Phase clocks of the kernel above (scratch/kbench_rb16.hip): 28 % of an item is "staging" -- the weight-gradient waves wait for their
 // prefetched words, apply the ReLU and write 8 x 16 bytes per thread to LDS while the conv waves idle.  A row of a tile is 32 pixels x 32
 // bytes = 1 KB, contiguous in HBM (NHWC) and in LDS: exactly ONE global_load_lds_dwordx4 wave-instruction (lane = 16-byte word of the
-// row), no registers, no LDS store instructions.  So: two tile buffers (2 x 45 KB); at the top of item k the weight-gradient waves issue the
-// 32 row DMAs of item k + 1 into the other buffer (a whole item of flight time), drain them (vmcnt(0)) just before the item's last barrier.
+// row), no registers, no LDS store instructions.  So: two tile buffers (16-row tiles: 2 x 79 KB = 161 KB, one workgroup per CU); at the top of
+// item k the weight-gradient waves issue the row DMAs (56 per 16-row item) of item k + 1 into the other buffer (a whole item of flight time), drain them (vmcnt(0)) just before the item's last barrier.
 // What changes for the consumers: relu(a) / relu(x) are no longer applied while staging -- the tiles hold RAW a and x; the ReLU masks
 // read them as before (> 0 is the same truth), the weight-gradient operand fragments take the ReLU in registers (one v_pk_max_i16 per
 // dword: max(x, 0) on bf16 bits = the staged relu, -0 -> +0 included).  Rows outside the image (first / last item of an image) are
@@ -1177,7 +1184,7 @@ template <int N> __device__ __forceinline__ void rb_wait_vm() { static_assert(N 
 __device__ unsigned short g_rb_zero_row[64 * 512];     // 64 x 1 KB of zeros: the DMA source of tile rows outside the image (one per workgroup mod 64:
                                                         // every workgroup reading the SAME 1 KB hit one L2 channel -- 352 vs 338 us per launch)
 #ifndef RBFULL16D_NBUF
-#define RBFULL16D_NBUF 3
+#define RBFULL16D_NBUF 2           // (three buffers of 8-row tiles measured like two: 340-352 vs 339-349 us)
 #endif
 #ifndef RBFULL16D_CG
 #define RBFULL16D_CG 5
@@ -1378,8 +1385,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16d_bf16_kernel(RbFul
                 __builtin_amdgcn_sched_barrier(0);
             }
             // this wave's row DMAs are older than its MT2 dx stores and the counter retires in order: all but the MT2 youngest done = rows landed
-            static_assert(C::MT2 == 4, "counted wait below");
-            rb_wait_vm<(NBUF - 2) * NC + 4>();
+            rb_wait_vm<(NBUF - 2) * NC + C::MT2>();
         } else {
             wgrad(s_y, 1, s_p, 10);                          // conv1's weight / bias gradient from (da, relu(x))
             rb_wait_vm<(NBUF - 2) * NWR>();                  // the NEXT item's rows have landed: all but the rows of the items after it
@@ -1421,18 +1427,17 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16d_bf16_kernel(RbFul
         sl2[C::WLEN + tid] = t2s; sl1[C::WLEN + tid] = t1s;
     }
 }
-// Which whole-backward kernel the 16-channel blocks run: 0 = resblock_bwd_full_bf16_kernel (256 threads, two workgroups per CU), 1 = the
-// wave-specialised one (register staging), 2 = wave-specialised + LDS-DMA into RBFULL16D_NBUF tile buffers.  Measured (round 3, us per
-// 8192-sample launch): micro-bench on random data 0: 348-362, 1: 368-376, 2: 330-352 (2 or 3 buffers alike); in the engine 0: 272-275,
-// 2: 261-270.  dx is bit-identical in all three.  The two-role kernels are one workgroup per CU and end up bound by the same thing as the
-// plain one -- how fast a CU gets its 41 KB per item through its load path (an item's rows cost ~150 cycles of issue each, and one
-// workgroup per CU has a single item's bytes in flight) -- so 3 % did not buy the extra machinery a place as the default.
+// Which whole-backward kernel the 16-channel blocks run (RBFULL16_SPECIALISED): 0 = resblock_bwd_full_bf16_kernel (256 threads, two
+// workgroups per CU), 1 = the wave-specialised one (register staging), 2 = wave-specialised + LDS-DMA into RBFULL16D_NBUF tile buffers
+// (DEFAULT, with 16-row tiles).  Measured (round 3, us per 8192-sample launch): micro-bench on random data 0: 348-371, 1: 368-376,
+// 2 with 8-row tiles: 330-363 (2 or 3 buffers alike), 2 with 16-row tiles: 346-347 where 0 ran 362-371; in the engine (HIP events, A/B of
+// library builds on one box, three rounds) 0: 272-278, 2 / 8 rows: 265-267, 2 / 16 rows: 258-263.  dx is bit-identical in all of them.
+// All variants end up bound by the same thing -- how fast a CU gets an item's bytes through its load path (a row's DMA costs its wave
+// ~150 cycles of issue: the queue drains at the CU's share of HBM) -- which is why fewer BYTES (16-row tiles: 36 instead of 41 KB per 8
+// rows) bought more than any re-arrangement of the work.
 // (Also tried on variant 2: two more waves, 640 threads, that only issue the row DMAs and wait for them -- the kernel then has to fit
 //  168 registers, spills 28-43 whatever the conv group size, and runs 560 us; issuing the rows from a run-time loop instead of the
 //  unrolled one: 415 against 335.)
-#ifndef RBFULL16_SPECIALISED
-#define RBFULL16_SPECIALISED 0
-#endif
 #ifndef RBFULL16S_BPC
 #define RBFULL16S_BPC 1            // workgroups per CU of the specialised kernel
 #endif
@@ -1456,7 +1461,9 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
         static std::once_flag attr_s;
         // one workgroup per CU: request more LDS than the tiles need so that a second workgroup never lands on the same CU (RBFULL16S_BPC == 1)
         constexpr size_t LDS_S = RBFULL16S_BPC == 1 ? (RbFull16S::LDS_BYTES > 84 * 1024 ? RbFull16S::LDS_BYTES : 84 * 1024) : RbFull16S::LDS_BYTES;
+#if RBFULL16_SPECIALISED == 1
         std::call_once(attr_s, [] { hipFuncSetAttribute((const void*)resblock_bwd_full16s_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_S); });
+#endif
         if (RBFULL16_SPECIALISED == 2) {
             static std::once_flag attr_d;
             constexpr size_t LDS_D = RBFULL16D_NBUF * RbFull16S::TILE_BYTES > RbFull16S::RED_BYTES ? RBFULL16D_NBUF * RbFull16S::TILE_BYTES : RbFull16S::RED_BYTES;
@@ -1465,7 +1472,9 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
             hipLaunchKernelGGL(resblock_bwd_full16d_bf16_kernel, dim3(grid), dim3(512), LDS_D, st, a);
             return;
         }
+#if RBFULL16_SPECIALISED == 1
         hipLaunchKernelGGL(resblock_bwd_full16s_bf16_kernel, dim3(grid), dim3(512), LDS_S, st, a);
+#endif
         return;
     }
     hipLaunchKernelGGL(resblock_bwd_full_bf16_kernel, dim3(grid), dim3(RbFull::NT), RbFull::LDS_BYTES, st, a);
