@@ -209,14 +209,11 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_roll_bf16_kernel(ConvArg
     auto load = [&](int w) {
         const long long img = blockIdx.x + (long long)(w / C::IPI) * gridDim.x; const int gy0 = 2 * (w % C::IPI) * 4 - 1;
 #pragma unroll
-        for (int k = 0; k < R::NLD; ++k) {
-            const int e = tid + k * 256;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (e < R::NSRC) {
-                const int c8 = e % C::C8, px = (e / C::C8) % C::HW, r = e / (C::C8 * C::HW), gy = gy0 + r;
-                if (gy >= 0 && gy < C::HW) v = *(const uint4*)(g_in + ((img * C::HW + gy) * C::HW + px) * C::CIN + c8 * 8);
-            }
-            regs[k] = v;
+        for (int k = 0; k < R::NLD; ++k) {                 // unconditional, from a clamped word / row (zeros are substituted at the LDS store): a conditional
+            int e = tid + k * 256; e = e < R::NSRC ? e : R::NSRC - 1;      // prefetch load is waited for where it is issued (DESIGN.md finding 11)
+            const int c8 = e % C::C8, px = (e / C::C8) % C::HW, r = e / (C::C8 * C::HW); int gy = gy0 + r;
+            gy = gy < 0 ? 0 : (gy > C::HW - 1 ? C::HW - 1 : gy);
+            regs[k] = *(const uint4*)(g_in + ((img * C::HW + gy) * C::HW + px) * C::CIN + c8 * 8);
         }
     };
     int abase[R::MT], cbase[R::MT];
@@ -234,8 +231,8 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_roll_bf16_kernel(ConvArg
         for (int k = 0; k < R::NLD; ++k) {
             const int e = tid + k * 256;
             if (e < R::NSRC) {
-                const int c8 = e % C::C8, px = (e / C::C8) % C::HW, r = e / (C::C8 * C::HW);
-                *(uint4*)(s_in + (r * C::PW + px + 1) * C::S + c8 * 8) = regs[k];
+                const int c8 = e % C::C8, px = (e / C::C8) % C::HW, r = e / (C::C8 * C::HW), gy = 2 * oy0 - 1 + r;
+                *(uint4*)(s_in + (r * C::PW + px + 1) * C::S + c8 * 8) = (gy >= 0 && gy < C::HW) ? regs[k] : (uint4){0u, 0u, 0u, 0u};
             }
         }
         if (tid < R::ROW_WORDS) {                          // key row 0: conv row 2 * oy0 - 1 = the previous step's last row, or row -1 of the image
@@ -243,7 +240,7 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_roll_bf16_kernel(ConvArg
             ((uint4*)s_c)[tid] = sub ? ((const uint4*)s_c)[8 * R::ROW_WORDS + tid] : mn;
         }
         __syncthreads();
-        if (w + 1 < nstep) load(w + 1);
+        load(w + 1 < nstep ? w + 1 : w);                   // (past the end: the last step again)
 
         f32x4 acc[R::MT][C::NB];
 #pragma unroll
