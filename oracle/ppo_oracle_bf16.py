@@ -70,7 +70,7 @@ def impala_backward(p, cache, dfeat_post, feat, rounding=True, dtype=torch.float
         fc_tn_kernel / fc_nt_kernel<true>); smaller batches take the fp32 GEMM with the fp32 fc.weight (engine.hip net_backward);
         fc.bias's gradient is the column sum of the unrounded d feat in both cases;
       * every activation gradient written to HBM or handed on through LDS is bf16: d flat, the gradient of a residual conv1's
-        output (da), of a block's input (dx), of the pre-pool conv output rebuilt from the pooled gradient (dc);
+        output (da), of a block's input (dx), of the pre-pool conv output rebuilt from the pooled gradient (dc; not block1's, see below);
       * data-gradient convs use the bf16 banks; weight gradients multiply bf16 operands exactly and accumulate in fp32."""
     r = _r16 if rounding else _ident
     p = {k: v.to(dtype) for k, v in p.items()}
@@ -109,7 +109,9 @@ def impala_backward(p, cache, dfeat_post, feat, rounding=True, dtype=torch.float
         # conv-output pixel are summed in fp32 and the sum is rounded (PoolStage::gather in conv_bf16.hip)
         dc = torch.zeros(B["cshape"][0], B["cshape"][1], B["cshape"][2] * B["cshape"][3], dtype=dtype)
         dc.scatter_add_(2, B["idx"].reshape(dc.shape[0], dc.shape[1], -1), gy.reshape(dc.shape[0], dc.shape[1], -1))
-        dc = r(dc.reshape(B["cshape"]))
+        # block1.conv (k == 0) takes its weight gradient from the pooled gradients in one-hot form (conv_bf16.hip
+        # conv1_wgrad_onehot_bf16_kernel): every g * x product is summed in fp32, the gathered sum is never rounded
+        dc = dc.reshape(B["cshape"]) if k == 0 else r(dc.reshape(B["cshape"]))
         w = p[b + ".conv.weight"]
         g[b + ".conv.weight"] = cw(B["xin"], w, dc)
         g[b + ".conv.bias"] = dc.sum(dim=(0, 2, 3))

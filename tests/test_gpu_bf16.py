@@ -103,11 +103,11 @@ def test_block1_conv_pool_fused_bf16(eng, n):
     assert np.array_equal(pooled, nhwc(y.detach()))
     dy = r16(torch.randn(y.shape, generator=torch.Generator().manual_seed(12)))
     y.backward(dy)
-    dc = r16(c.grad)                                                                      # the fused staging rounds the gathered sum to bf16
-    ref_w = torch.nn.grad.conv2d_weight(x, w.shape, dc, padding=1)
+    dc = c.grad            # one-hot form (conv1_wgrad_onehot_bf16_kernel): the pooled gradients multiply the frame pixels directly, the <= 4
+    ref_w = torch.nn.grad.conv2d_weight(x, w.shape, dc, padding=1)      # contributions of a conv pixel are never summed into a bf16 first
     gw, gb = eng.op_conv3x3(4, 3, 16, 64, w.numpy(), inp=x_u8, bias=b.numpy(), dout=nhwc(dy))
-    assert relerr(gw, ref_w.numpy()) < 1e-4
-    assert relerr(gb, dc.sum(dim=(0, 2, 3)).numpy()) < 1e-4
+    assert relerr(gw, ref_w.numpy()) < 2e-5
+    assert relerr(gb, dc.sum(dim=(0, 2, 3)).numpy()) < 2e-5
 
 
 @pytest.mark.parametrize("cin,cout,hw", [(16, 32, 32), (32, 32, 16)])

@@ -1392,6 +1392,228 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
     float* slab = a.partial + (long long)blockIdx.x * 448;
     for (int e = tid; e < 448; e += 256) slab[e] = red[e];
 }
+// ---- block1.conv weight gradient from the POOLED gradient in ONE-HOT form (round 3; replaces the gather of conv1_wgrad_bf16_kernel<true>)
+// dW[co][tap][ci] = sum_p dC[p][co] x[p + tap][ci], and the max-pool backward is dC[p][co] = sum of g[w][co] over the windows w whose
+// arg-max is p.  Substituted:  dW = sum_{w, pos} T[w][pos][co] x[pixel(w, pos) + tap][ci]  with  T[w][pos][co] = (arg[w][co] == pos) ?
+// g[w][co] : 0  -- the pool backward becomes a one-hot EXPANSION of the contraction index (9 K-rows per window: 9216 per image instead
+// of 4096 pixels) whose operand addresses are regular: pixel(w, pos) = (2 oy - 1 + ky, 2 ox - 1 + kx) does not depend on the data.  No
+// gathered dC tile, no compare / select / add per (window position, channel): the old kernel spent ~75 vector instructions per conv
+// pixel there and was VALU-issue-bound at 2.6 TB/s with 8 % of the matrix pipe busy.  Numerically the products g * x are summed in fp32
+// directly (the old form rounded the <= 4 coinciding contributions of a pixel to one bf16 first): closer to the fp32 reference.
+//   * item = 4 pooled rows of one image (8 items per image); wave r owns pooled row r: 8 K-steps of 4 windows x positions 0..7 and one
+//     K-step of 32 windows x position 8;
+//   * positions 0..7 -- the A operand (16 channels x 32 K-rows) is built in REGISTERS: lane (co, kq) reads g and arg of window 4 s + kq
+//     (two small LDS reads) and places g in the slot arg of its 8; position 8 -- a second one-hot image T8[w][co], written once per item;
+//   * B operand = frame pixels through ds_read_b64_tr_b16 as in the old kernel: lane (rq, cp) of quarter kq supplies the 8-byte LDS row of
+//     pixel(window, position rq | 4 + rq) + tap(4 m + cp); the 16 columns of MFMA m are 4 taps x (3 channels + the 1.0 that sums the bias);
+//   * two LDS tile sets and two staging register sets: item k + 1 is stored while item k is multiplied, loads run two items ahead,
+//     one barrier per item.
+#ifndef C1H_EXP
+#define C1H_EXP 0
+#endif
+#ifndef C1H_TWAVE
+#define C1H_TWAVE 0
+#endif
+#ifdef WG_TIMING
+#define TCKH(k) do { if (tid == 64 * C1H_TWAVE) { const long long now_ = clock64(); tacc_[k] += now_ - tlast_; tlast_ = now_; } } while (0)
+#else
+#define TCKH(k) do { } while (0)
+#endif
+#ifndef C1H_PW
+#define C1H_PW 72                  // pixels per tile row: 72 x 8 bytes = 16 banks more per row -- the <= 3 rows x 7 pixels a half-wave's B read touches fall on distinct banks
+#endif
+struct C1H {
+    static constexpr int R = 4, TPI = 32 / R;                  // pooled rows per item, items per image
+    static constexpr int PH = 2 * R + 3, PW = C1H_PW;           // tile row 0 = image row 2 oy0 - 2, tile column 0 = image column -2 (68 needed)
+    static constexpr int NTASK = PH * 16;                      // 12-byte frame pieces (4 pixels) of an item
+    static constexpr int IN_BYTES = PH * PW * 8, G_BYTES = R * 32 * 16 * 2, A_BYTES = R * 32 * 16, T8_BYTES = G_BYTES;
+    static constexpr int SET_BYTES = IN_BYTES + G_BYTES + A_BYTES + T8_BYTES;
+    static_assert(NTASK <= 256 && R * 32 * 2 == 256, "one frame piece and one 8-channel gradient chunk per thread");
+    static_assert(IN_BYTES % 16 == 0 && SET_BYTES % 16 == 0, "16-byte aligned tile sets");
+};
+typedef unsigned c1h_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void conv1_wgrad_onehot_bf16_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c1h[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = i >> 2, cp = i & 3;
+    const unsigned short* g_dp = (const unsigned short*)a.dout;
+    const int nwork = a.n * C1H::TPI, G = gridDim.x;
+    if ((int)blockIdx.x >= nwork) {                             // (the slab count is the old kernel's: min(1024, 16 n) >= 8 n)
+        float* slab = a.partial + (long long)blockIdx.x * 448;
+        for (int e = tid; e < 448; e += 256) slab[e] = 0.f;
+        return;
+    }
+#ifdef WG_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = clock64();
+#endif
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int e = tid; e < 2 * C1H::SET_BYTES / 16; e += 256) ((uint4*)smem_c1h)[e] = (uint4){0u, 0u, 0u, 0u};      // halo columns stay zero
+    struct Stage { uint32_t px[3]; uint4 g; uint2 ar; };
+    Stage S0, S1;
+    const int ftid = tid;          // thread of frame piece ftid (rotating the three waves that hold the 176 pieces with the workgroup: no change, 184-198 us)
+    auto item = [&](int w) { return w < nwork ? w : nwork - 1; };          // past the end: the last item again (loads stay unconditional)
+    auto load = [&](Stage& S, int w, long long frame) {
+        const int img = w / C1H::TPI, oy0 = (w % C1H::TPI) * C1H::R;
+        const int row = (ftid >> 4) < C1H::PH ? (ftid >> 4) : C1H::PH - 1, gy = 2 * oy0 - 2 + row, gyc = gy < 0 ? 0 : (gy > 63 ? 63 : gy);
+        const uint32_t* p = (const uint32_t*)((const uint8_t*)a.in + frame * (64 * 64 * 3) + gyc * 192 + (ftid & 15) * 12);
+        S.px[0] = p[0]; S.px[1] = p[1]; S.px[2] = p[2];
+        const size_t o = ((size_t)img * 32 + oy0) * 512 + (size_t)tid * 8;
+        S.g = *(const uint4*)(g_dp + o); S.ar = *(const uint2*)(a.pool_arg + o);
+    };
+    auto hot8 = [](unsigned gd, unsigned b_lo, unsigned b_hi) { return (b_lo == 8u ? (gd & 0xffffu) : 0u) | (b_hi == 8u ? (gd & 0xffff0000u) : 0u); };
+    auto store = [&](const Stage& S, unsigned char* set, int w) {
+        const int oy0 = (w % C1H::TPI) * C1H::R;
+        if (ftid < C1H::NTASK && C1H_EXP != 5) {
+            unsigned short* s_in = (unsigned short*)set;
+            const int row = ftid >> 4, gy = 2 * oy0 - 2 + row;
+            const bool in = gy >= 0 && gy < 64;
+            const uint32_t px[3] = {in ? S.px[0] : 0u, in ? S.px[1] : 0u, in ? S.px[2] : 0u};      // rows outside the image: zeros
+            mi_f32x2 f[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                f[b] = (mi_f32x2){(float)((px[(2 * b) >> 2] >> (8 * ((2 * b) & 3))) & 0xffu), (float)((px[(2 * b + 1) >> 2] >> (8 * ((2 * b + 1) & 3))) & 0xffu)}
+                       * (mi_f32x2){1.0f / 255.0f, 1.0f / 255.0f};
+            auto fv = [&](int b) { return (b & 1) ? f[b >> 1].y : f[b >> 1].x; };
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(uint2*)(s_in + (row * C1H::PW + 2 + (ftid & 15) * 4 + j) * 4) = (uint2){mi_pk_bf16(fv(3 * j), fv(3 * j + 1)), mi_pk_bf16(fv(3 * j + 2), 1.f)};
+        }
+        *(uint4*)(set + C1H::IN_BYTES + tid * 16) = S.g;
+        *(uint2*)(set + C1H::IN_BYTES + C1H::G_BYTES + tid * 8) = S.ar;
+        if (C1H_EXP == 6) return;
+        const uint4 t8 = {hot8(S.g.x, S.ar.x & 0xffu, (S.ar.x >> 8) & 0xffu), hot8(S.g.y, (S.ar.x >> 16) & 0xffu, S.ar.x >> 24),
+                          hot8(S.g.z, S.ar.y & 0xffu, (S.ar.y >> 8) & 0xffu), hot8(S.g.w, (S.ar.y >> 16) & 0xffu, S.ar.y >> 24)};
+        *(uint4*)(set + C1H::IN_BYTES + C1H::G_BYTES + C1H::A_BYTES + tid * 16) = t8;
+    };
+    // lane constants (byte offsets inside a tile set); this wave's pooled row = wave
+    int offB[2][3], off8B[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int t = (4 * m + cp) < 9 ? 4 * m + cp : 8, ty = t / 3, tx = t % 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pos = 4 * h + rq, ky = pos / 3, kx = pos % 3;
+            offB[h][m] = ((2 * wave + ky + ty) * C1H::PW + 2 * kq + kx + tx) * 8;
+        }
+        off8B[m] = ((2 * wave + 2 + ty) * C1H::PW + 2 * (8 * kq + rq) + 2 + tx) * 8;
+    }
+    const int offG = C1H::IN_BYTES + ((wave * 32 + kq) * 16 + i) * 2, offA = C1H::IN_BYTES + C1H::G_BYTES + (wave * 32 + kq) * 16 + i;
+    const int off8A = C1H::IN_BYTES + C1H::G_BYTES + C1H::A_BYTES + ((wave * 32 + 8 * kq + rq) * 16 + 4 * cp) * 2;
+    // operand fragments of one K-step, fetched one step ahead of their MFMAs (the LDS latency of a step hides behind the previous one)
+    struct Frag { s16x4 lo[3], hi[3]; unsigned g16, ab; s16x4 alo, ahi; };
+    auto fetch = [&](Frag& F, const unsigned char* set, int s) {
+        if (s < 8) {                                            // windows 4 s + kq, positions 0..7
+            F.g16 = *(const unsigned short*)(set + offG + s * 128); F.ab = *(const unsigned char*)(set + offA + s * 64);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+#if C1H_EXP == 3          // timing experiment: two of the six B reads
+                if (m > 0) { F.lo[m] = F.lo[0]; F.hi[m] = F.hi[0]; continue; }
+#endif
+                F.lo[m] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(set + offB[0][m] + s * 64));
+                F.hi[m] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(set + offB[1][m] + s * 64));
+            }
+        } else {                                                // position 8 of the row's 32 windows: slots 0..3 = windows 8 kq + rq, 4..7 = + 4
+            F.alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(set + off8A));
+            F.ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(set + off8A + 128));
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                F.lo[m] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(set + off8B[m]));
+                F.hi[m] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(set + off8B[m] + 64));
+            }
+        }
+    };
+    auto mul = [&](const Frag& F, int s) {
+        bf16x8 av;
+        if (s < 8) {                                            // slot j of the lane's 8 = position j: g goes to slot arg
+#if C1H_EXP == 1          // timing experiment: no one-hot placement
+            const c1h_u32x4 aw = {F.g16, F.ab, F.g16, F.ab};
+#else
+            const unsigned val = F.g16 << ((F.ab & 1u) * 16u), d = F.ab >> 1;
+            const c1h_u32x4 aw = {d == 0u ? val : 0u, d == 1u ? val : 0u, d == 2u ? val : 0u, d == 3u ? val : 0u};
+#endif
+            av = __builtin_bit_cast(bf16x8, aw);
+        } else
+            av = __builtin_shufflevector(F.alo, F.ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+#if C1H_EXP == 2          // timing experiment: one MFMA instead of three
+        for (int m = 0; m < 1; ++m) { const bf16x8 bv = __builtin_shufflevector(F.lo[m], F.hi[m], 0, 1, 2, 3, 4, 5, 6, 7) ^ __builtin_shufflevector(F.lo[1], F.hi[1], 0, 1, 2, 3, 4, 5, 6, 7) ^ __builtin_shufflevector(F.lo[2], F.hi[2], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[m] = MFMA_BF16(av, bv, acc[m]); }
+#else
+        for (int m = 0; m < 3; ++m) acc[m] = MFMA_BF16(av, __builtin_shufflevector(F.lo[m], F.hi[m], 0, 1, 2, 3, 4, 5, 6, 7), acc[m]);
+#endif
+    };
+    auto compute = [&](const unsigned char* set) {
+        Frag F0, F1;
+        fetch(F0, set, 0);
+#pragma unroll
+        for (int s = 0; s < 8; s += 2) {
+            fetch(F1, set, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(F0, s);
+            fetch(F0, set, s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(F1, s + 1);
+        }
+        mul(F0, 8);
+    };
+    unsigned char* const set0 = smem_c1h;
+    unsigned char* const set1 = smem_c1h + C1H::SET_BYTES;
+    int work = blockIdx.x, frame_next;
+    {
+        const int w1 = item(work + G), w2 = item(work + 2 * G);
+        load(S0, work, c1_frame(a.idx, a.in_base, work / C1H::TPI));
+        load(S1, w1, c1_frame(a.idx, a.in_base, w1 / C1H::TPI));
+        __syncthreads();                                        // the zero fill
+        store(S0, set0, work);
+        load(S0, w2, c1_frame(a.idx, a.in_base, w2 / C1H::TPI));
+        frame_next = c1_frame_fetch(a.idx, a.in, item(work + 3 * G) / C1H::TPI);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the prologue's index loads are the youngest: drain once here, not in the loop
+        __syncthreads();
+    }
+    // `work` is multiplied from set_cur while S (item work + G) goes to set_nxt and is re-loaded with item work + 3 G
+    auto iter = [&](int work, Stage& S, unsigned char* set_cur, unsigned char* set_nxt) {
+        TCKH(0);
+        store(S, set_nxt, item(work + G));
+        TCKH(1);
+        {
+            const int w3 = item(work + 3 * G);
+            const long long frame = c1_frame_of(a.idx, a.in_base, frame_next, w3 / C1H::TPI);
+            frame_next = c1_frame_fetch(a.idx, a.in, item(work + 4 * G) / C1H::TPI);
+            load(S, w3, frame);
+        }
+        TCKH(2);
+#if C1H_EXP != 4
+        compute(set_cur);
+#endif
+        TCKH(3);
+        __syncthreads();
+    };
+    for (; work + G < nwork; work += 2 * G) { iter(work, S1, set0, set1); iter(work + G, S0, set1, set0); }
+    if (work < nwork) iter(work, S1, set0, set1);
+#ifdef WG_TIMING
+    if (tid == 64 * C1H_TWAVE) for (int k = 0; k < 8; ++k) atomicAdd(&g_wg_timing[k], (unsigned long long)tacc_[k]);
+#endif
+    float* red = (float*)smem_c1h;                 // 432 weights + 16 bias sums (the ones column)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {          // column i of MFMA m = (tap 4m + i/4, channel i%4); channel 3 of the centre tap = bias sum
+                    const int tap = 4 * m + (i >> 2), ci = i & 3;
+                    if (tap < 9 && (ci < 3 || tap == 4)) {
+                        const int o = (ci < 3) ? (kq * 4 + r) * 27 + tap * 3 + ci : 432 + kq * 4 + r;
+                        red[o] = (w == 0) ? acc[m][r] : red[o] + acc[m][r];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    float* slab = a.partial + (long long)blockIdx.x * 448;
+    for (int e = tid; e < 448; e += 256) slab[e] = red[e];
+}
+#ifndef C1_WG_ONEHOT
+#define C1_WG_ONEHOT 1             // 0: the gathering kernel conv1_wgrad_bf16_kernel<true>
+#endif
 #ifndef C1_WG_PAD
 #define C1_WG_PAD (36 * 1024)      // requested LDS: at most 4 workgroups of the 1024 land on one CU (an even spread; the tiles need 12-16 KB)
 #endif
@@ -1409,10 +1631,12 @@ void launch_conv1_wgrad_bf16(const WgradArgs& a, const unsigned short* lut16, hi
     std::call_once(attr, [] {
         hipFuncSetAttribute((const void*)conv1_wgrad_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_WG_LDS);
         hipFuncSetAttribute((const void*)conv1_wgrad_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_WGP_LDS);
+        hipFuncSetAttribute((const void*)conv1_wgrad_onehot_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C1H::SET_BYTES);
     });
     const int grid = c1_grid(a.n);
     if (grid < 1) return;
-    if (a.pool_arg) hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<true>, dim3(grid), dim3(256), C1_WGP_LDS, st, a, lut16);
+    if (a.pool_arg && C1_WG_ONEHOT) hipLaunchKernelGGL(conv1_wgrad_onehot_bf16_kernel, dim3(grid), dim3(256), 2 * C1H::SET_BYTES, st, a);
+    else if (a.pool_arg) hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<true>, dim3(grid), dim3(256), C1_WGP_LDS, st, a, lut16);
     else hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<false>, dim3(grid), dim3(256), C1_WG_LDS, st, a, lut16);
 }
 
