@@ -32,6 +32,13 @@ int main(int argc, char** argv) {
     hipEventRecord(e1, st); hipStreamSynchronize(st);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const int grid = RB32_SPECIALISED && spec ? rb_full32s_grid(n) : rb_full32_grid_t<RbFull32>(n);
+    { std::vector<unsigned short> hd(X); hipMemcpy(hd.data(), dx, X * 2, hipMemcpyDeviceToHost);
+      std::vector<float> hs((size_t)2 * 1024 * 9248); hipMemcpy(hs.data(), slabs, hs.size() * 4, hipMemcpyDeviceToHost);
+      unsigned long long h1 = 1469598103934665603ull, h2 = h1;
+      for (size_t k = 0; k < X; ++k) h1 = (h1 ^ hd[k]) * 1099511628211ull;
+      const int g = RB32_SPECIALISED && spec ? rb_full32s_grid(n) : rb_full32_grid_t<RbFull32>(n);
+      for (int l = 0; l < 2; ++l) for (size_t k = 0; k < (size_t)g * 9248; ++k) { unsigned u; memcpy(&u, &hs[(size_t)l * 1024 * 9248 + k], 4); h2 = (h2 ^ u) * 1099511628211ull; }
+      printf("hash dx %016llx slabs %016llx\n", h1, h2); }
     printf("%s n=%d grid=%d: %.1f us/launch  (%s)\n", spec ? "specialised" : "plain", n, grid, ms * 1000 / reps, hipGetErrorString(hipGetLastError()));
 #ifdef WG_TIMING
     if (spec) {

@@ -1001,13 +1001,17 @@ __device__ __forceinline__ void c1_store(const uint32_t (&r)[C1::NLD], unsigned 
     const int e = threadIdx.x, row = e >> 4, g = e & 15, gy = ty0 + row - 1;
     if (e < C1::NTASK) {
         const bool in = gy >= 0 && gy < C1::HW;
-        float f[12];
+        const uint32_t px[3] = {in ? r[0] : 0u, in ? r[1] : 0u, in ? r[2] : 0u};      // rows outside the image: zeros (3 selects instead of 12)
+        mi_f32x2 f[6];                                                               // 6 packed multiplies instead of 12
 #pragma unroll
-        for (int b = 0; b < 12; ++b) f[b] = in ? (float)((r[b >> 2] >> (8 * (b & 3))) & 0xffu) * (1.0f / 255.0f) : 0.f;
+        for (int b = 0; b < 6; ++b)
+            f[b] = (mi_f32x2){(float)((px[(2 * b) >> 2] >> (8 * ((2 * b) & 3))) & 0xffu), (float)((px[(2 * b + 1) >> 2] >> (8 * ((2 * b + 1) & 3))) & 0xffu)}
+                   * (mi_f32x2){1.0f / 255.0f, 1.0f / 255.0f};
+        auto fv = [&](int b) { return (b & 1) ? f[b >> 1].y : f[b >> 1].x; };
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *(uint2*)(s_in + (row * C1::PW + 1 + g * 4 + j) * 4) =
-                (uint2){mi_pk_bf16(f[3 * j], f[3 * j + 1]), mi_pk_bf16(f[3 * j + 2], ONE4 ? 1.f : 0.f)};
+                (uint2){mi_pk_bf16(fv(3 * j), fv(3 * j + 1)), mi_pk_bf16(fv(3 * j + 2), ONE4 ? 1.f : 0.f)};
     }
 }
 
@@ -1050,13 +1054,13 @@ __global__ __launch_bounds__(256) void conv1_fwd_bf16_kernel(ConvArgs a, const u
             const uint2 lo = *(const uint2*)(p + off0), hi = *(const uint2*)(p + off1), t8 = *(const uint2*)(p + off8);
             const bf16x8 a1 = __builtin_bit_cast(bf16x8, (uint4){lo.x, lo.y, hi.x, hi.y});
             const bf16x8 a2 = __builtin_bit_cast(bf16x8, (uint4){t8.x, t8.y, 0u, 0u});
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = {bias, bias, bias, bias};                 // the bias is the accumulator's initial value (as in the fused conv + pool kernel)
             acc = MFMA_BF16(a1, bw1, acc);
             acc = MFMA_BF16(a2, bw2, acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int po = (wave * 8 + mt) * 16 + kq * 4 + r;
-                g_out[(((long long)img * C1::HW + ty0 + po / C1::TW) * C1::HW + po % C1::TW) * 16 + i] = f2bf(acc[r] + bias);
+                g_out[(((long long)img * C1::HW + ty0 + po / C1::TW) * C1::HW + po % C1::TW) * 16 + i] = f2bf(acc[r]);
             }
         }
     }
@@ -1144,7 +1148,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
     static_assert((C1P::NPIX * 4) % 8 == 0, "16-byte zero fill");
     for (int e = tid; e < C1P::NPIX * 4 / 8; e += 256) ((uint4*)s_in)[e] = (uint4){0u, 0u, 0u, 0u};
     if (tid < 9 * 8) ((unsigned*)s_c)[(tid >> 3) * 65 * (C1P_SC / 2) + (tid & 7)] = MI_KEY_MIN2;
-    float bias4[4];                                        // output channels 4*kq .. 4*kq+3 (the MFMA's row quad)
+    f32x4 bias4;                                           // output channels 4*kq .. 4*kq+3 (the MFMA's row quad): the accumulators' initial value
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias4[r] = a.bias ? a.bias[kq * 4 + r] : 0.f;
     int off0, off1;
@@ -1188,18 +1192,23 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
                 const int pl = (wave * 9 + mt) * 16 + i, y = pl / 64, x = pl % 64;
                 const unsigned short* p = s_in + (y * C1P::PW + x) * 4;
                 const uint2 lo = *(const uint2*)(p + off0), hi = *(const uint2*)(p + off1), t8 = *(const uint2*)(p + off8);
-                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-                acc[m] = MFMA_BF16(bw1, __builtin_bit_cast(bf16x8, (uint4){lo.x, lo.y, hi.x, hi.y}), zero4);
+                acc[m] = MFMA_BF16(bw1, __builtin_bit_cast(bf16x8, (uint4){lo.x, lo.y, hi.x, hi.y}), bias4);
                 acc[m] = MFMA_BF16(bw2, __builtin_bit_cast(bf16x8, (uint4){t8.x, t8.y, 0u, 0u}), acc[m]);
             }
 #pragma unroll
             for (int m = 0; m < C1P_GROUP; ++m) {
-                const int t = wave * 9 + g0 + m;                 // tiles 0..3 = conv row 0 of the item: outside the image when cy0 == -1
-                const bool dead = cy0 < 0 && t < 4;
-                const unsigned k0 = mi_bf16x2_to_keys(mi_pk_bf16(acc[m][0] + bias4[0], acc[m][1] + bias4[1]));
-                const unsigned k1 = mi_bf16x2_to_keys(mi_pk_bf16(acc[m][2] + bias4[2], acc[m][3] + bias4[3]));
-                *(uint2*)(s_c + (t * 16 + i + (t >> 2) + 1) * C1P_SC + kq * 4) = (uint2){dead ? MI_KEY_MIN2 : k0, dead ? MI_KEY_MIN2 : k1};
+                const int t = wave * 9 + g0 + m;
+                const unsigned k0 = mi_bf16x2_to_keys(mi_pk_bf16(acc[m][0], acc[m][1]));
+                const unsigned k1 = mi_bf16x2_to_keys(mi_pk_bf16(acc[m][2], acc[m][3]));
+                *(uint2*)(s_c + (t * 16 + i + (t >> 2) + 1) * C1P_SC + kq * 4) = (uint2){k0, k1};
             }
+        }
+        // tiles 0..3 = conv row 0 of the item, outside the image when cy0 == -1 (an image's first item): minimal keys over what wave 0 has
+        // just written there (its own LDS stores, in order) -- one branch per item instead of two selects per tile
+        if (cy0 < 0 && wave == 0) {
+            unsigned* q = (unsigned*)(s_c + (lane + 1) * C1P_SC);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) q[w] = MI_KEY_MIN2;
         }
         TCK(5);
         __syncthreads();
