@@ -1468,7 +1468,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_onehot_bf16_kernel(WgradArgs 
         const size_t o = ((size_t)img * 32 + oy0) * 512 + (size_t)tid * 8;
         S.g = *(const uint4*)(g_dp + o); S.ar = *(const uint2*)(a.pool_arg + o);
     };
-    auto hot8 = [](unsigned gd, unsigned b_lo, unsigned b_hi) { return (b_lo == 8u ? (gd & 0xffffu) : 0u) | (b_hi == 8u ? (gd & 0xffff0000u) : 0u); };
     auto store = [&](const Stage& S, unsigned char* set, int w) {
         const int oy0 = (w % C1H::TPI) * C1H::R;
         if (ftid < C1H::NTASK && C1H_EXP != 5) {
@@ -1488,9 +1487,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_onehot_bf16_kernel(WgradArgs 
         }
         *(uint4*)(set + C1H::IN_BYTES + tid * 16) = S.g;
         *(uint2*)(set + C1H::IN_BYTES + C1H::G_BYTES + tid * 8) = S.ar;
-        if (C1H_EXP == 6) return;
-        const uint4 t8 = {hot8(S.g.x, S.ar.x & 0xffu, (S.ar.x >> 8) & 0xffu), hot8(S.g.y, (S.ar.x >> 16) & 0xffu, S.ar.x >> 24),
-                          hot8(S.g.z, S.ar.y & 0xffu, (S.ar.y >> 8) & 0xffu), hot8(S.g.w, (S.ar.y >> 16) & 0xffu, S.ar.y >> 24)};
+        // position 8 <=> bit 3 of the arg byte (values 0..8): byte masks 0x00 / 0xff, each spread over its channel's 16-bit half
+        const unsigned m0 = (S.ar.x >> 3) & 0x01010101u, m1 = (S.ar.y >> 3) & 0x01010101u, mm0 = (m0 << 8) - m0, mm1 = (m1 << 8) - m1;
+        const uint4 t8 = {S.g.x & __builtin_amdgcn_perm(mm0, mm0, 0x01010000u), S.g.y & __builtin_amdgcn_perm(mm0, mm0, 0x03030202u),
+                          S.g.z & __builtin_amdgcn_perm(mm1, mm1, 0x01010000u), S.g.w & __builtin_amdgcn_perm(mm1, mm1, 0x03030202u)};
         *(uint4*)(set + C1H::IN_BYTES + C1H::G_BYTES + C1H::A_BYTES + tid * 16) = t8;
     };
     // lane constants (byte offsets inside a tile set); this wave's pooled row = wave
@@ -1579,7 +1579,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_onehot_bf16_kernel(WgradArgs 
         __syncthreads();
     }
     // `work` is multiplied from set_cur while S (item work + G) goes to set_nxt and is re-loaded with item work + 3 G
-    auto iter = [&](int work, Stage& S, unsigned char* set_cur, unsigned char* set_nxt) {
+    auto iter = [&](int work_, Stage& S, unsigned char* set_cur, unsigned char* set_nxt) {
+        const int work = __builtin_amdgcn_readfirstlane(work_);      // uniform: item / image / row arithmetic on the scalar unit, the index fetch a scalar load
         TCKH(0);
         store(S, set_nxt, item(work + G));
         TCKH(1);
