@@ -1943,6 +1943,251 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full32s_bf16_kernel(RbFul
     }
 }
 
+// ---- 8x8 images, FOUR per item, wave-specialised (round 3).  The kernel above handles ONE 8x8 image per item: 256 threads, one pixel tile
+// per wave and conv -- every tile re-reads its conv's whole filter bank from LDS (18 KB of bank for 9 KB of pixels), three barriers per
+// image, and the launch ran 67-73 us for 17 MB of tensors at 12 % matrix-pipe activity.  Here an item is four images (256 pixels, the
+// pixel count of a 16x16 image) in the two-role scheme of resblock_bwd_full32s_bf16_kernel: conv waves 0-3 hold both transposed banks in
+// registers and take four pixel tiles per conv, weight-gradient waves 4-7 stage the tiles (every staged row is inside its image: plain
+// unconditional loads) and walk the item's eight 32-pixel steps with their columns.  LDS: per image four 10-row tiles (dy with its
+// zero rows -1 and 8 -- da is only needed on the image's own rows --, d(conv1 output), relu(conv1 output), relu(block input)), 153.6 KB.
+// Arithmetic per output element unchanged (same banks, same K order): dx is bit-identical to the kernel above; the slabs sum the same
+// products in another order of partial sums.
+struct RbFull32Q {
+    static constexpr int C = 32, HW = 8, NIMG = 4, S = RB_S32, P = HW + 2, R = HW + 2;          // rows -1 .. 8 of every tile
+    static constexpr int IMG_ELEMS = R * P * S, T_ELEMS = NIMG * IMG_ELEMS;                     // one image's / the item's share of a tile
+    static constexpr int NK = 9, WS = NK * 32 + 16;
+    static constexpr int NMT = NIMG * HW * HW / 16, MTW = NMT / 4;                              // 16 pixel tiles, 4 per conv wave
+    static constexpr int NW16 = NIMG * HW * HW * 4, KW = NW16 / 256;                            // 16-byte words per tensor and item; per staging thread (4)
+    static constexpr int NSTEP = NIMG * HW * HW / 32;                                           // 8 pixel steps of 32
+    static constexpr int NQ = 18, WLEN = C * 9 * C, SLAB = WLEN + C;
+    static constexpr size_t LDS_BYTES = (size_t)4 * T_ELEMS * 2;
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+};
+__global__ __launch_bounds__(512, 2) void resblock_bwd_full32q_bf16_kernel(RbFullArgs a) {
+    using C = RbFull32Q;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_x = smem_h;                         // dy, rows -1 .. 8 of each image (rows -1 and 8 stay zero)
+    unsigned short* s_y = s_x + C::T_ELEMS;               // d(conv1 output)
+    unsigned short* s_a = s_y + C::T_ELEMS;               // relu(conv1 output)
+    unsigned short* s_p = s_a + C::T_ELEMS;               // relu(block input)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool conv_role = wv < 4;
+    const int rw = wv & 3;
+#ifdef WG_TIMING
+    long long tacc_[4] = {0, 0, 0, 0}, tlast_ = clock64();
+#endif
+    for (int e = tid; e < 4 * C::T_ELEMS / 8; e += 512) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};      // halo rows / columns stay zero
+    // one register array for both roles, as in the 16x16 kernel: conv role st[2m + nb] / st[18 + 2m + nb] = bank fragments of conv2 / conv1;
+    // weight-gradient role st[2qq + cb] / st[10 + 2qq + cb] accumulators, st[20 + cb] bias accumulators, st[22 .. 33] the 12 prefetch words
+    constexpr int NST = 36, QM = 5;
+    static_assert(22 + 3 * C::KW <= NST, "prefetch words fit behind the accumulators");
+    f32x4 st[NST];
+    const int qcnt = (C::NQ - rw + 3) / 4;
+    if (conv_role) {
+#pragma unroll
+        for (int m = 0; m < 9; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                st[2 * m + nb] = __builtin_bit_cast(f32x4, *(const uint4*)(a.bank2_t + (nb * 16 + i) * C::WS + m * 32 + kq * 8));
+                st[18 + 2 * m + nb] = __builtin_bit_cast(f32x4, *(const uint4*)(a.bank1_t + (nb * 16 + i) * C::WS + m * 32 + kq * 8));
+            }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NST; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the fragments are in (see the 16x16 kernel)
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    auto koffc = [](int m) { return ((m / 3) * C::P + (m % 3)) * C::S; };
+    // pixel pl (0 .. 255) of the item: image pl / 64, row (pl % 64) / 8, column pl % 8; element offset of its WINDOW ORIGIN (row - 1, column - 1) in a tile
+    auto porg = [](int pl) { return ((pl >> 6) * C::R + ((pl >> 3) & 7)) * C::P * C::S + (pl & 7) * C::S; };
+    constexpr int CENTER = (C::P + 1) * C::S;
+
+    const int nwork = (a.n + C::NIMG - 1) / C::NIMG;
+    const int t2 = tid - 256;                             // staging thread: word e = t2 + 256 k of each tensor = (pixel e / 4, 8-channel chunk e % 4)
+    auto load = [&](int work) {
+        const int img0 = work * C::NIMG;
+#pragma unroll
+        for (int k = 0; k < C::KW; ++k) {
+            const int e = t2 + k * 256, pl = e >> 2;
+            const int n = img0 + (pl >> 6) < a.n ? img0 + (pl >> 6) : a.n - 1;        // images past the end: a valid one, replaced by zeros at the store
+            const long long o = ((long long)n * 64 + (pl & 63)) * C::C + (e & 3) * 8;
+            st[22 + k] = __builtin_bit_cast(f32x4, *(const uint4*)(a.dy + o));
+            st[22 + C::KW + k] = __builtin_bit_cast(f32x4, *(const uint4*)(a.a_fwd + o));
+            st[22 + 2 * C::KW + k] = __builtin_bit_cast(f32x4, *(const uint4*)(a.x_fwd + o));
+        }
+    };
+    // one pixel step (32 pixels = half an image) of a layer's weight gradient, operands as in the 16x16 kernel.  The step loops below are
+    // unrolled by 4, not 8: fully unrolled, the compiler hoists every step's operand addresses out of the item loop and 54 registers
+    // spill (rolled 56.9, by 2 54.4, by 4 53.8 us per 8192 images).  Issuing the reads of step t + 1 before the MFMAs of step t by hand:
+    // 59.6 us -- the phases do not wait for these reads.
+    auto wg_step = [&](int t, const unsigned short* s_d, const unsigned short* s_src, const int a0, bool bias) {
+        int orow[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) orow[h] = porg(32 * t + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq) + 4 * cp;
+        auto tr = [&](const unsigned short* base, int off) {
+            const rb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + orow[0] + off));
+            const rb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rb_lds_s16x4_ptr)(base + orow[1] + off));
+            return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8 d[2], b[QM];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) d[cb] = tr(s_d, CENTER + cb * 16);
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq) {
+            const int q = rw + 4 * (qq < 4 ? qq : (qcnt > 4 ? 4 : 0)), tap = q >> 1, ib = q & 1;
+            b[qq] = tr(s_src, koffc(tap) + ib * 16);
+        }
+        asm volatile("" ::: "memory");
+        if (bias) { st[20] = MFMA_BF16(d[0], ones, st[20]); st[21] = MFMA_BF16(d[1], ones, st[21]); }
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq)
+            if (qq < qcnt) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) st[a0 + 2 * qq + cb] = MFMA_BF16(d[cb], b[qq], st[a0 + 2 * qq + cb]);
+            }
+    };
+
+    if (!conv_role && (int)blockIdx.x < nwork) load(blockIdx.x);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int img0 = work * C::NIMG, left = a.n - img0;           // images of this item that exist
+        __syncthreads();
+        RTCK(3);
+        if (!conv_role) {
+#pragma unroll
+            for (int k = 0; k < C::KW; ++k) {
+                const int e = t2 + k * 256, pl = e >> 2;
+                const int o = porg(pl) + CENTER + (e & 3) * 8;
+                const bool on = (pl >> 6) < left;
+                const uint4 z = {0u, 0u, 0u, 0u};
+                const uint4 vx = on ? __builtin_bit_cast(uint4, st[22 + k]) : z, va = on ? __builtin_bit_cast(uint4, st[22 + C::KW + k]) : z,
+                            vp = on ? __builtin_bit_cast(uint4, st[22 + 2 * C::KW + k]) : z;
+                *(uint4*)(s_x + o) = vx;
+                *(uint4*)(s_a + o) = (uint4){rb_relu2(va.x), rb_relu2(va.y), rb_relu2(va.z), rb_relu2(va.w)};
+                *(uint4*)(s_p + o) = (uint4){rb_relu2(vp.x), rb_relu2(vp.y), rb_relu2(vp.z), rb_relu2(vp.w)};
+            }
+        }
+        __syncthreads();
+        RTCK(0);
+        if (!conv_role && work + (int)gridDim.x < nwork) load(work + gridDim.x);
+
+        if (conv_role) {
+            // ---- da = convT2(dy) * (a > 0) on the images' own rows -> s_y: tiles rw, rw + 4, rw + 8, rw + 12, one at a time (weights in registers)
+            for (int t = rw; t < C::NMT; t += 4) {
+                const int org = porg(t * 16 + i);
+                const unsigned short* src = s_x + org + kq * 8;
+                const int yb = org + CENTER + kq * 4;
+                bf16x8 av[5];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) av[m] = *(const bf16x8*)(src + koffc(m));
+                const uint2 mk0 = *(const uint2*)(s_a + yb), mk1 = *(const uint2*)(s_a + yb + 16);
+                asm volatile("" ::: "memory");
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int m = 0; m < 9; ++m) {
+                    const bf16x8 cur = av[m % 5];
+                    acc[0] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[2 * m]), cur, acc[0]);
+                    acc[1] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[2 * m + 1]), cur, acc[1]);
+                    if (m < 4) av[m] = *(const bf16x8*)(src + koffc(m + 5));
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const uint2 mk = nb ? mk1 : mk0;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rb_lane(mk, r) > 0.f ? acc[nb][r] : 0.f;
+                    const uint2 raw = rb_pack(v);
+                    *(uint2*)(s_y + yb + nb * 16) = raw;
+                    if (a.da_out) {
+                        const int pl = t * 16 + i;
+                        if ((pl >> 6) < left) *(uint2*)(a.da_out + ((long long)img0 * 64 + pl) * C::C + nb * 16 + kq * 4) = raw;
+                    }
+                }
+            }
+        } else {
+            // ---- conv2's weight / bias gradient from (dy, relu(a))
+#pragma unroll 4
+            for (int t = 0; t < C::NSTEP; ++t) wg_step(t, s_x, s_a, 0, rw == 2);
+        }
+        RTCK(1);
+        __syncthreads();
+        RTCK(2);
+        if (conv_role) {
+            // ---- dx = convT1(da) * (x > 0) + dy -> HBM
+            for (int t = rw; t < C::NMT; t += 4) {
+                const int pl = t * 16 + i, org = porg(pl);
+                const unsigned short* src = s_y + org + kq * 8;
+                const int eo = org + CENTER + kq * 4;
+                bf16x8 av[5];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) av[m] = *(const bf16x8*)(src + koffc(m));
+                const uint2 mk0 = *(const uint2*)(s_p + eo), mk1 = *(const uint2*)(s_p + eo + 16);
+                const uint2 sk0 = *(const uint2*)(s_x + eo), sk1 = *(const uint2*)(s_x + eo + 16);
+                asm volatile("" ::: "memory");
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int m = 0; m < 9; ++m) {
+                    const bf16x8 cur = av[m % 5];
+                    acc[0] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[18 + 2 * m]), cur, acc[0]);
+                    acc[1] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[18 + 2 * m + 1]), cur, acc[1]);
+                    if (m < 4) av[m] = *(const bf16x8*)(src + koffc(m + 5));
+                }
+                if ((pl >> 6) < left) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const uint2 mk = nb ? mk1 : mk0, sk = nb ? sk1 : sk0;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (rb_lane(mk, r) > 0.f ? acc[nb][r] : 0.f) + rb_lane(sk, r);
+                        *(uint2*)(a.dx_out + ((long long)img0 * 64 + pl) * C::C + nb * 16 + kq * 4) = rb_pack(v);
+                    }
+                }
+            }
+        } else {
+            // ---- conv1's weight / bias gradient from (da, relu(x))
+#pragma unroll 4
+            for (int t = 0; t < C::NSTEP; ++t) wg_step(t, s_y, s_p, 10, rw == 3);
+        }
+    }
+#ifdef WG_TIMING
+    if ((tid & 255) == 0) for (int q = 0; q < 4; ++q) atomicAdd(&g_rb_timing[(tid >> 8) * 4 + q], (unsigned long long)tacc_[q]);
+#endif
+    if (!conv_role) {
+        float* sl2 = a.slab2 + (long long)blockIdx.x * C::SLAB;
+        float* sl1 = a.slab1 + (long long)blockIdx.x * C::SLAB;
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq)
+            if (qq < qcnt) {
+                const int q = rw + 4 * qq, tap = q >> 1, ib = q & 1;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = ((cb * 16 + kq * 4 + r) * 9 + tap) * C::C + ib * 16 + i;
+                        sl2[o] = st[2 * qq + cb][r]; sl1[o] = st[10 + 2 * qq + cb][r];
+                    }
+            }
+        if (i == 0 && rw >= 2) {
+            float* sl = rw == 2 ? sl2 : sl1;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sl[C::WLEN + cb * 16 + kq * 4 + r] = st[20 + cb][r];
+        }
+    }
+}
+#ifndef RB32_QUAD8
+#define RB32_QUAD8 1               // 8x8 blocks: 1 = resblock_bwd_full32q_bf16_kernel (four images per item), 0 = one image per item (kernel above)
+#endif
+static int rb_full32q_grid(int n) { const int w = (n + RbFull32Q::NIMG - 1) / RbFull32Q::NIMG; return w > 256 ? 256 : w; }
+static void launch_rb_full32q(const RbFullArgs& a, hipStream_t st) {
+    static std::once_flag attr;
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_bwd_full32q_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbFull32Q::LDS_BYTES); });
+    const int grid = rb_full32q_grid(a.n);
+    if (grid < 1) return;
+    hipLaunchKernelGGL(resblock_bwd_full32q_bf16_kernel, dim3(grid), dim3(512), RbFull32Q::LDS_BYTES, st, a);
+}
+
 template <class C>
 static int rb_full32_grid_t(int n) {
     int bpc = (int)((160 * 1024) / C::LDS_BYTES);
@@ -1954,7 +2199,7 @@ static int rb_full32_grid_t(int n) {
 #define RB32_SPECIALISED 1
 #endif
 static int rb_full32s_grid(int n);
-int resblock_bwd_full32_grid(ConvShape s, int n) { return s == CS_32_32_16 ? (RB32_SPECIALISED ? rb_full32s_grid(n) : rb_full32_grid_t<RbFull32>(n)) : s == CS_32_32_8 ? rb_full32_grid_t<RbFull32S>(n) : -1; }
+int resblock_bwd_full32_grid(ConvShape s, int n) { return s == CS_32_32_16 ? (RB32_SPECIALISED ? rb_full32s_grid(n) : rb_full32_grid_t<RbFull32>(n)) : s == CS_32_32_8 ? (RB32_QUAD8 ? rb_full32q_grid(n) : rb_full32_grid_t<RbFull32S>(n)) : -1; }
 template <class C>
 static void launch_rb_full32_t(const RbFullArgs& a, hipStream_t st) {
     static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
@@ -1982,7 +2227,7 @@ void launch_resblock_bwd_full32_bf16(ConvShape s, const void* dy, const void* a_
     RbFullArgs a{(const unsigned short*)dy, (const unsigned short*)a_fwd, (const unsigned short*)x_fwd, (unsigned short*)dx_out, (unsigned short*)da_out,
                  bank2_t, bank1_t, slab2, slab1, n};
     if (s == CS_32_32_16) { if (RB32_SPECIALISED) launch_rb_full32s(a, st); else launch_rb_full32_t<RbFull32>(a, st); }
-    else if (s == CS_32_32_8) launch_rb_full32_t<RbFull32S>(a, st);
+    else if (s == CS_32_32_8) { if (RB32_QUAD8) launch_rb_full32q(a, st); else launch_rb_full32_t<RbFull32S>(a, st); }
 }
 
 // res1 + res2 of a block forward in one launch.  b / bank: res1.conv1, res1.conv2, res2.conv1, res2.conv2 (forward banks).
