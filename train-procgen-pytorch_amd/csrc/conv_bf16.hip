@@ -581,6 +581,193 @@ static void launch_block2_conv_bwd(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(block2_conv_bwd_bf16_kernel, dim3(grid), dim3(B2Bwd::NT), B2Bwd::LDS, st, a);
 }
 
+// ------------------------------------------------------------------------------------------ block3.conv: whole backward in one launch
+// Data gradient AND weight / bias gradient of block3.conv (32 -> 32 channels @16x16) from the POOLED output gradient (8x8) + arg-max
+// bytes.  Until round 3 two generic launches did this (weight gradient 80 us + data gradient 77 us per 8192 samples), each with its own
+// max-pool-backward gather and one small image per item.  Here: two images per item, 512 threads in the two-role scheme of the residual
+// blocks' whole-backward kernels -- all eight waves stage and gather (PoolStage::gather_task2, the arithmetic of the generic kernels: the
+// conv-output gradient tile is bit-identical), then waves 0-3 run the transposed conv with the bank in registers (18 fragments, 8 pixel
+// tiles per wave) while waves 4-7 run the weight gradient (16 pixel steps of 32, (tap, input block) columns dealt to the waves, bias
+// through a tile of 1.0s).  dX is bit-identical to the generic data-gradient kernel (same bank, same tap order).
+struct B3Bwd {
+    using PS = PoolStage<32, 8, 9>;                                         // pooled rows 0..7 + one row of "no window" (arg 0xff)
+    static constexpr int NT = 512, NIMG = 2, HW = 16, P = HW + 2, S = 48;  // S: pixel stride (bf16 elements) of the 32-channel tiles
+    static constexpr int T_ELEMS = P * P * S;                               // a haloed 16x16x32 tile
+    static constexpr int PD_ALL = PS::PD_ELEMS + (PS::PD_ELEMS + 1) / 2;    // pooled stage of one image in bf16 elements (gradient + arg bytes)
+    static constexpr int WS = 9 * 32 + 16, WLEN = 32 * 9 * 32, SLAB = WLEN + 32;
+    static constexpr int NMT = NIMG * HW * HW / 16, NSTEP = NIMG * HW * HW / 32;      // 32 pixel tiles, 16 pixel steps
+    static constexpr size_t LDS = (size_t)NIMG * (2 * T_ELEMS + PD_ALL) * 2;
+    static_assert(LDS <= 160 * 1024 && PD_ALL % 8 == 0, "one workgroup per CU; 16-byte aligned stages");
+    static_assert(PS::NTASK2 == 1024, "two gather tasks per thread and image");
+};
+__global__ __launch_bounds__(512, 2) void block3_conv_bwd_bf16_kernel(ConvArgs a) {
+    using K = B3Bwd; using PS = K::PS;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_dc = smem_h;                                          // [NIMG] gathered conv-output gradient, haloed
+    unsigned short* s_xi = s_dc + K::NIMG * K::T_ELEMS;                     // [NIMG] forward input, haloed
+    unsigned short* s_pd = s_xi + K::NIMG * K::T_ELEMS;                     // [NIMG] pooled gradient (bf16) + arg-max bytes
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kq = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool conv_role = wv < 4;
+    const int rw = wv & 3;
+    const unsigned short* g_dp = (const unsigned short*)a.in;
+    const unsigned short* g_xi = (const unsigned short*)a.wg_in;
+    unsigned short* g_out = (unsigned short*)a.out;
+    for (int e = tid; e < (int)(K::LDS / 16); e += K::NT) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};      // tile borders stay zero
+    __syncthreads();
+    for (int e = tid; e < K::NIMG * 8 * 32; e += K::NT)                     // pooled row 8 does not exist: an arg-max that matches no position
+        ((uint8_t*)(s_pd + (e >> 8) * K::PD_ALL + PS::PD_ELEMS))[8 * 8 * 32 + (e & 255)] = 0xff;
+    // one register array for both roles: conv role st[2m + nb] = fragment (tap m, output block nb) of the transposed bank;
+    // weight-gradient role st[2qq + cb] = accumulator tile of this wave's column qq and output block cb, st[20 + cb] = bias accumulators
+    constexpr int NST = 22, QM = 5;
+    f32x4 st[NST];
+    const int qcnt = (18 - rw + 3) / 4;                                     // columns q = rw + 4 qq of the 18 (tap, input block) columns: 5, 5, 4, 4
+    if (conv_role) {
+#pragma unroll
+        for (int m = 0; m < 9; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) st[2 * m + nb] = __builtin_bit_cast(f32x4, *(const uint4*)(a.wbank + (nb * 16 + i) * K::WS + m * 32 + kq * 8));
+#pragma unroll
+        for (int q = 18; q < NST; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int q = 0; q < NST; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0): the fragments are in
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (uint4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    auto koffc = [](int m) { return ((m / 3) * K::P + (m % 3)) * K::S; };
+    // pixel pl (0 .. 511) of the item: image pl / 256, row (pl / 16) % 16, column pl % 16 -> element offset of its window origin in a tile pair
+    auto porg = [](int pl) { return (pl >> 8) * K::T_ELEMS + (((pl >> 4) & 15) * K::P + (pl & 15)) * K::S; };
+    constexpr int CENTER = (K::P + 1) * K::S;
+
+    const int nwork = (a.n + K::NIMG - 1) / K::NIMG;
+    typedef unsigned b3_u32x4 __attribute__((ext_vector_type(4)));            // (ext-vector typed: an array of the HIP uint4 STRUCT copied global -> local -> LDS goes through scratch memory)
+    typedef unsigned b3_u32x2 __attribute__((ext_vector_type(2)));
+    b3_u32x4 rx[4], rg; b3_u32x2 ra;                                        // staging registers of both roles: 4 input words, one pooled-gradient word + its arg bytes
+    auto load = [&](int work) {
+        const int img0 = work * K::NIMG;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + k * K::NT, pl = e >> 2;
+            const int n = img0 + (pl >> 8) < a.n ? img0 + (pl >> 8) : a.n - 1;       // an image past the end: a valid one, zeroed at the store
+            rx[k] = *(const b3_u32x4*)(g_xi + ((long long)n * 256 + (pl & 255)) * 32 + (e & 3) * 8);
+        }
+        const int n = img0 + (tid >> 8) < a.n ? img0 + (tid >> 8) : a.n - 1;
+        const long long o = (long long)n * 2048 + (tid & 255) * 8;
+        rg = *(const b3_u32x4*)(g_dp + o); ra = *(const b3_u32x2*)(a.pool_arg + o);
+    };
+    auto wg_step = [&](int t) {
+        int orow[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) orow[h] = porg(32 * t + 16 * (kq >> 1) + 8 * h + 4 * (kq & 1) + rq) + 4 * cp;
+        auto tr = [&](const unsigned short* base, int off) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + orow[0] + off));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + orow[1] + off));
+            return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8 d[2], b[QM];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) d[cb] = tr(s_dc, CENTER + cb * 16);
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq) {
+            const int q = rw + 4 * (qq < 4 ? qq : (qcnt > 4 ? 4 : 0)), tap = q >> 1, ib = q & 1;
+            b[qq] = tr(s_xi, koffc(tap) + ib * 16);
+        }
+        asm volatile("" ::: "memory");
+        if (rw == 2) { st[20] = MFMA_BF16(d[0], ones, st[20]); st[21] = MFMA_BF16(d[1], ones, st[21]); }
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq)
+            if (qq < qcnt) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) st[2 * qq + cb] = MFMA_BF16(d[cb], b[qq], st[2 * qq + cb]);
+            }
+    };
+
+    if ((int)blockIdx.x < nwork) load(blockIdx.x);
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int img0 = work * K::NIMG, left = a.n - img0;                  // images of this item that exist
+        __syncthreads();                                                     // the previous item's readers are done
+        {
+            const b3_u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = tid + k * K::NT, pl = e >> 2;
+                *(b3_u32x4*)(s_xi + porg(pl) + CENTER + (e & 3) * 8) = (pl >> 8) < left ? rx[k] : z;
+            }
+            unsigned short* pd = s_pd + (tid >> 8) * K::PD_ALL;
+            *(b3_u32x4*)(pd + (tid & 255) * 8) = (tid >> 8) < left ? rg : z;
+            *(b3_u32x2*)((uint8_t*)(pd + PS::PD_ELEMS) + (tid & 255) * 8) = ra;
+        }
+        __syncthreads();
+        // max-pool backward of both images into the haloed tiles (conv rows 0..15 -> tile rows 1..16), two tasks per thread and image
+#pragma unroll
+        for (int im = 0; im < K::NIMG; ++im)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                PS::gather_task2(s_pd + im * K::PD_ALL, tid + j * K::NT, 0, -1000, 1000, s_dc + im * K::T_ELEMS, -1, K::P, 1, K::S);
+        if (work + (int)gridDim.x < nwork) load(work + gridDim.x);
+        __syncthreads();
+        if (conv_role) {
+            // ---- dX = convT(dC): tiles rw, rw + 4, ... of the 32, one at a time (weights in registers)
+            for (int t = rw; t < K::NMT; t += 4) {
+                const int pl = t * 16 + i;
+                const unsigned short* src = s_dc + porg(pl) + kq * 8;
+                bf16x8 av[5];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) av[m] = *(const bf16x8*)(src + koffc(m));
+                asm volatile("" ::: "memory");
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int m = 0; m < 9; ++m) {
+                    const bf16x8 cur = av[m % 5];
+                    acc[0] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[2 * m]), cur, acc[0]);
+                    acc[1] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[2 * m + 1]), cur, acc[1]);
+                    if (m < 4) av[m] = *(const bf16x8*)(src + koffc(m + 5));
+                }
+                if ((pl >> 8) < left) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        *(uint2*)(g_out + ((long long)img0 * 256 + pl) * 32 + nb * 16 + kq * 4) =
+                            (uint2){mi_pk_bf16(acc[nb][0], acc[nb][1]), mi_pk_bf16(acc[nb][2], acc[nb][3])};
+                }
+            }
+        } else {
+            // ---- weight / bias gradient from (dC, forward input)
+#pragma unroll 4
+            for (int t = 0; t < K::NSTEP; ++t) wg_step(t);
+        }
+    }
+    if (!conv_role) {                                                        // every weight-gradient wave owns its columns: straight to the slab
+        float* sl = a.wg_partial + (long long)blockIdx.x * K::SLAB;
+#pragma unroll
+        for (int qq = 0; qq < QM; ++qq)
+            if (qq < qcnt) {
+                const int q = rw + 4 * qq, tap = q >> 1, ib = q & 1;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sl[((cb * 16 + kq * 4 + r) * 9 + tap) * 32 + ib * 16 + i] = st[2 * qq + cb][r];
+            }
+        if (i == 0 && rw == 2) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sl[K::WLEN + cb * 16 + kq * 4 + r] = st[20 + cb][r];
+        }
+    }
+}
+#ifndef B3BWD_FUSED
+#define B3BWD_FUSED 1              // 0: block3.conv's two gradients stay two generic launches
+#endif
+static int b3bwd_grid(int n) { const int w = (n + B3Bwd::NIMG - 1) / B3Bwd::NIMG; return w > 256 ? 256 : w; }
+static void launch_block3_conv_bwd(const ConvArgs& a, hipStream_t st) {
+    static std::once_flag attr;
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)block3_conv_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3Bwd::LDS); });
+    const int grid = b3bwd_grid(a.n);
+    if (grid < 1) return;
+    hipLaunchKernelGGL(block3_conv_bwd_bf16_kernel, dim3(grid), dim3(B3Bwd::NT), B3Bwd::LDS, st, a);
+}
+
 // ------------------------------------------------------------------------------------------ filter-bank packing
 int bank_ws(int cin_pass) { return (cin_pass == 32 ? 9 : 5) * 32 + 16; }
 __global__ void pack_banks_kernel(const float* __restrict__ params, unsigned short* __restrict__ banks, const BankDesc* __restrict__ desc) {
@@ -1697,10 +1884,11 @@ void launch_conv_dgrad_bf16(ConvShape s, const ConvArgs& a, hipStream_t st) {
         case CS_16_16_32: launch_bf_t<BD_16_16_32>(a, st); break;
         case CS_16_32_32: if (a.pool_arg && a.wg_partial) launch_block2_conv_bwd(a, st);
                           else if (a.pool_arg) launch_bf_t<BD_16_32_32, true>(a, st); else launch_bf_t<BD_16_32_32>(a, st); break;
-        case CS_32_32_16: if (a.pool_arg) launch_bf_t<BD_32_32_16, true>(a, st); else launch_bf_t<BD_32_32_16>(a, st); break;
+        case CS_32_32_16: if (a.pool_arg && a.wg_partial) launch_block3_conv_bwd(a, st);
+                          else if (a.pool_arg) launch_bf_t<BD_32_32_16, true>(a, st); else launch_bf_t<BD_32_32_16>(a, st); break;
         case CS_32_32_8:  launch_bf_t<BD_32_32_8>(a, st); break;
         default: break;
     }
 }
 
-int conv_bwd_fused_grid(ConvShape s, int n) { return s == CS_16_32_32 ? b2bwd_grid(n) : -1; }
+int conv_bwd_fused_grid(ConvShape s, int n) { return s == CS_16_32_32 ? b2bwd_grid(n) : (s == CS_32_32_16 && B3BWD_FUSED) ? b3bwd_grid(n) : -1; }
