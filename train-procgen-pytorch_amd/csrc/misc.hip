@@ -400,7 +400,7 @@ __global__ __launch_bounds__(1024) void reduce_all_slabs_kernel(const float* __r
     __syncthreads();
     if (g == 0 && e < d.slab_len) {
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 8                                                   // (all 32 reads in flight spilled 8 registers to scratch memory)
         for (int k = 0; k < 32; ++k) t += sh[k][ex];
         float* dst = (e < d.n_w) ? grads + d.w_off + e : grads + d.b_off + e - d.n_w;
         dst[0] += t.x; dst[1] += t.y; dst[2] += t.z; dst[3] += t.w;

@@ -1189,6 +1189,12 @@ __device__ unsigned short g_rb_zero_row[64 * 512];     // 64 x 1 KB of zeros: th
 #ifndef RBFULL16D_CG
 #define RBFULL16D_CG 5
 #endif
+#ifndef RBFULL16D_INTERLEAVE
+#define RBFULL16D_INTERLEAVE 1
+#endif
+#ifndef RBFULL16D_N1
+#define RBFULL16D_N1 10             // rows (of a weight-gradient wave's 14) issued during phase 1; the rest during phase 2 (engine, us per launch: all up front 268, 14: 256, 10: 249)
+#endif
 #ifndef RBFULL16D_NC
 #define RBFULL16D_NC 0             // tile rows (of 32) whose DMA each conv wave issues (measured: 0 best -- 338 us; 2 / 3 / 4: 374-387 / 376-380 / 365-371)
 #endif
@@ -1235,30 +1241,38 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16d_bf16_kernel(RbFul
     // (issuing one row costs its wave ~150 cycles -- 1 KB through the CU's load path -- so the rows are dealt to BOTH roles: NC per conv
     //  wave, the rest to the weight-gradient waves, whose phases are the shorter ones)
     constexpr int NROW = C::XR + 2 * C::YR, NC = RBFULL16D_NC, NWR = (NROW - 4 * NC + 3) / 4;
-    auto fill = [&](int work, int b) {
+    // row jj (of this wave's share) of item `work` -> buffer b
+    auto fill_row = [&](int work, int b, int jj) {
         const long long img = work / C::TPI; const int ty0 = (work % C::TPI) * C::TH;
+        if (jj >= (conv_role ? NC : NWR)) return;           // (wave-uniform)
+        const int j = conv_role ? 4 * NWR + rw + 4 * jj : rw + 4 * jj;
+        if (j >= NROW) return;
+        const int t = j < C::XR ? 0 : (j < C::XR + C::YR ? 1 : 2), ry = j - (t == 0 ? 0 : (t == 1 ? C::XR : C::XR + C::YR));
+        const int gy = ty0 - (t == 0 ? 2 : 1) + ry;
+        // element offset of the row's first interior pixel inside the buffer: s_x | s_y | s_a | s_p
+        const int eoff = (t == 0 ? 0 : (t == 1 ? C::X_ELEMS + C::Y_ELEMS : C::X_ELEMS + 2 * C::Y_ELEMS)) + (ry * C::P + 1) * C::S;
+        // a row outside the image comes from a row of zeros: every wave then issues the SAME number of DMAs per item, so the counted
+        // wait for "all but the younger items' rows" is an immediate
+        const unsigned short* src = (gy >= 0 && gy < C::HW) ? (t == 0 ? a.dy : (t == 1 ? a.a_fwd : a.x_fwd)) + ((img * C::HW + gy) * C::HW) * C::C + lane * 8
+                                                            : g_rb_zero_row + (blockIdx.x & 63) * 512 + lane * 8;
+        rb_glds16(src, lds0 + (unsigned)(b * TILE + eoff) * 2u);
+    };
+    auto fill = [&](int work, int b) {
 #pragma unroll
-        for (int jj = 0; jj < (NC > NWR ? NC : NWR); ++jj) {
-            if (jj >= (conv_role ? NC : NWR)) continue;     // (wave-uniform)
-            const int j = conv_role ? 4 * NWR + rw + 4 * jj : rw + 4 * jj;
-            if (j >= NROW) continue;
-            const int t = j < C::XR ? 0 : (j < C::XR + C::YR ? 1 : 2), ry = j - (t == 0 ? 0 : (t == 1 ? C::XR : C::XR + C::YR));
-            const int gy = ty0 - (t == 0 ? 2 : 1) + ry;
-            // element offset of the row's first interior pixel inside the buffer: s_x | s_y | s_a | s_p
-            const int eoff = (t == 0 ? 0 : (t == 1 ? C::X_ELEMS + C::Y_ELEMS : C::X_ELEMS + 2 * C::Y_ELEMS)) + (ry * C::P + 1) * C::S;
-            // a row outside the image comes from a row of zeros: every wave then issues the SAME number of DMAs per item, so the counted
-            // wait for "all but the younger items' rows" is an immediate
-            const unsigned short* src = (gy >= 0 && gy < C::HW) ? (t == 0 ? a.dy : (t == 1 ? a.a_fwd : a.x_fwd)) + ((img * C::HW + gy) * C::HW) * C::C + lane * 8
-                                                                : g_rb_zero_row + (blockIdx.x & 63) * 512 + lane * 8;
-            rb_glds16(src, lds0 + (unsigned)(b * TILE + eoff) * 2u);
-        }
+        for (int jj = 0; jj < (NC > NWR ? NC : NWR); ++jj) fill_row(work, b, jj);
     };
     auto relu8 = [](bf16x8 v) {
         const uint4 u = __builtin_bit_cast(uint4, v);
         return __builtin_bit_cast(bf16x8, (uint4){rb_relu2_max(u.x), rb_relu2_max(u.y), rb_relu2_max(u.z), rb_relu2_max(u.w)});
     };
     // weight gradient of one layer over this wave's NR consecutive pixel rows: d = output-gradient tile (row offset d_row), b = RAW input tile
-    auto wgrad = [&](const unsigned short* s_d, int d_row, const unsigned short* s_b, const int a0) {
+    // RBFULL16D_INTERLEAVE: conv2's weight gradient (phase 1) issues the NEXT item's row DMAs between its MFMA groups, a few per pixel row --
+    // issued back to back at the top of the item they cost the wave ~190 cycles each (the CU's load path drains at its share of HBM and the
+    // wave waits for queue space), 2600 cycles per item in front of phase 1 while the conv waves waited at the mid barrier.
+    // The first N1 rows go out during phase 1, the rest during phase 2 (whose weight-gradient work is the shorter role's).
+    constexpr int N1 = RBFULL16D_N1 < NWR ? RBFULL16D_N1 : NWR;
+    auto wgrad = [&](const unsigned short* s_d, int d_row, const unsigned short* s_b, const int a0, int fill_work, int fill_b, const int f_lo, const int f_hi) {
+        const int FPR = (f_hi - f_lo + C::NR + 1) / (C::NR + 2);      // DMAs per pixel-row iteration (NR + 2 iterations cover rows f_lo .. f_hi - 1)
         const int r0 = C::NR * rw;
         int ocol[2];
 #pragma unroll
@@ -1278,6 +1292,11 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16d_bf16_kernel(RbFul
             bf16x8 fb[3];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) fb[kx] = relu8(tr(s_b, ((r0 + R) * C::P + kx) * C::S));
+            if (RBFULL16D_INTERLEAVE) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    if (f < FPR && f_lo + R * FPR + f < f_hi) fill_row(fill_work, fill_b, f_lo + R * FPR + f);
+            }
 #pragma unroll
             for (int j = 0; j < C::NR; ++j) {
                 const int ky = R - j;
@@ -1302,7 +1321,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16d_bf16_kernel(RbFul
         unsigned short* s_a = s_y + C::Y_ELEMS;
         unsigned short* s_p = s_a + C::Y_ELEMS;
         S16_TCK(3);                                         // (phase-2 work + wait at the end barrier of the previous item)
-        fill(item(work + (NBUF - 1) * gridDim.x), (b + NBUF - 1) % NBUF);      // that buffer's readers (item k - 1) finished before the barrier that ended the previous item
+        if (!RBFULL16D_INTERLEAVE || conv_role) fill(item(work + (NBUF - 1) * gridDim.x), (b + NBUF - 1) % NBUF);      // that buffer's readers (item k - 1) finished before the barrier that ended the previous item
         S16_TCK(0);                                         // DMA issue
         if (conv_role) {
             // ---- da = convT2(dy) * (a > 0) on rows ty0-1 .. ty0+TH -> s_y
@@ -1346,7 +1365,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16d_bf16_kernel(RbFul
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            wgrad(s_x, 2, s_a, 0);                           // conv2's weight / bias gradient from (dy, relu(a))
+            wgrad(s_x, 2, s_a, 0, item(work + (NBUF - 1) * gridDim.x), (b + NBUF - 1) % NBUF, 0, N1);      // conv2's weight / bias gradient from (dy, relu(a)) + the next item's first rows
         }
         S16_TCK(1);                                         // phase-1 work
         rb_raw_barrier();                                   // da is complete (LDS only: the DMAs of the next item stay in flight)
@@ -1387,7 +1406,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full16d_bf16_kernel(RbFul
             // this wave's row DMAs are older than its MT2 dx stores and the counter retires in order: all but the MT2 youngest done = rows landed
             rb_wait_vm<(NBUF - 2) * NC + C::MT2>();
         } else {
-            wgrad(s_y, 1, s_p, 10);                          // conv1's weight / bias gradient from (da, relu(x))
+            wgrad(s_y, 1, s_p, 10, item(work + (NBUF - 1) * gridDim.x), (b + NBUF - 1) % NBUF, N1, NWR);      // conv1's weight / bias gradient from (da, relu(x)) + the remaining rows
             rb_wait_vm<(NBUF - 2) * NWR>();                  // the NEXT item's rows have landed: all but the rows of the items after it
         }
         rb_raw_barrier();                                   // everyone is done with this buffer; the other one is complete
