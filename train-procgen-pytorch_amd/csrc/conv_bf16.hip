@@ -1313,7 +1313,7 @@ void launch_repack_all(const float* params, unsigned short* banks, const BankDes
     const int blocks = 8 * n_desc + (16 * C1_WS + 255) / 256 + 256 * 2048 / 256;
     hipLaunchKernelGGL(repack_all_kernel, dim3(blocks), dim3(256), 0, st, params, banks, d_desc, n_desc, c1_w, c1_bank, fc_w, fc_wp, fc_wt);
 }
-__global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, const unsigned short* lut16, unsigned short* p_out, uint8_t* p_arg) {
+__global__ __launch_bounds__(256, 4) void conv1_pool_fwd_bf16_kernel(ConvArgs a, const unsigned short* lut16, unsigned short* p_out, uint8_t* p_arg) {      // 4 waves per SIMD: <= 128 registers (140 cost a workgroup per CU)
     __shared__ __attribute__((aligned(16))) unsigned short s_in[C1P::NPIX * 4];
     __shared__ __attribute__((aligned(16))) unsigned short s_w[16 * C1_WS];
     // conv-output tile as ORDER-PRESERVING KEYS (common.h), [9 rows][1 pad + 64 px][16 ch]: the pad cell is column -1 of its row
@@ -1342,14 +1342,21 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
     { const int t0 = 2 * kq, t1 = 2 * kq + 1; off0 = ((t0 / 3) * C1P::PW + t0 % 3) * 4; off1 = ((t1 / 3) * C1P::PW + t1 % 3) * 4; }
     constexpr int off8 = (2 * C1P::PW + 2) * 4;
     const int nwork = a.n * 8;                             // 8 groups of 4 pooled rows per image
-    uint32_t regs[C1P::NLD];
+    // Two staging register sets: the frame rows of item k + 2 are requested while item k is processed.  An item lasts about one loaded
+    // memory round trip, so with a single set the staging phase waited for its own data (20 % of the phase clocks).
+    uint32_t regs0[C1P::NLD], regs1[C1P::NLD];
     auto item = [&](int w) { return w < nwork ? w : nwork - 1; };          // past the end: the last item again (loads stay unconditional)
+    const int G = gridDim.x;
     int frame_next = 0;
     if ((int)blockIdx.x < nwork) {
-        c1_load<C1P>(regs, (const uint8_t*)a.in, c1_frame(a.idx, a.in_base, blockIdx.x / 8), (blockIdx.x % 8) * 8 - 1);
-        frame_next = c1_frame_fetch(a.idx, a.in, item(blockIdx.x + gridDim.x) / 8);
+        const int w0 = blockIdx.x, w1 = item(w0 + G);
+        c1_load<C1P>(regs0, (const uint8_t*)a.in, c1_frame(a.idx, a.in_base, w0 / 8), (w0 % 8) * 8 - 1);
+        c1_load<C1P>(regs1, (const uint8_t*)a.in, c1_frame(a.idx, a.in_base, w1 / 8), (w1 % 8) * 8 - 1);
+        frame_next = c1_frame_fetch(a.idx, a.in, item(w0 + 2 * G) / 8);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the prologue's index loads are the youngest: drain once here, not in the loop
     }
-    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+    auto step = [&](int work_, uint32_t (&regs)[C1P::NLD]) {
+        const int work = __builtin_amdgcn_readfirstlane(work_);               // uniform (a lambda parameter would live in a vector register)
         const int img = work / 8, oy0 = (work % 8) * 4, cy0 = 2 * oy0 - 1;      // first conv row of this item (may be -1)
         TCK(0);
         __syncthreads();
@@ -1358,8 +1365,8 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
         TCK(2);
         __syncthreads();
         TCK(3);
-        { const int w2 = item(work + gridDim.x); c1_load<C1P>(regs, (const uint8_t*)a.in, c1_frame_of(a.idx, a.in_base, frame_next, w2 / 8), (w2 % 8) * 8 - 1);
-          frame_next = c1_frame_fetch(a.idx, a.in, item(work + 2 * gridDim.x) / 8); }
+        { const int w2 = item(work + 2 * G); c1_load<C1P>(regs, (const uint8_t*)a.in, c1_frame_of(a.idx, a.in_base, frame_next, w2 / 8), (w2 % 8) * 8 - 1);
+          frame_next = c1_frame_fetch(a.idx, a.in, item(work + 3 * G) / 8); }
         TCK(4);
         const bf16x8 bw1 = *(const bf16x8*)(s_w + i * C1_WS + kq * 8);
         const bf16x8 bw2 = *(const bf16x8*)(s_w + i * C1_WS + 32 + kq * 8);
@@ -1416,7 +1423,10 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_bf16_kernel(ConvArgs a, co
             *(uint2*)(p_arg + o) = ar;
         }
         TCK(7);
-    }
+    };
+    int work = blockIdx.x;
+    for (; work + G < nwork; work += 2 * G) { step(work, regs0); step(work + G, regs1); }      // (a conditional second step would merge two load histories)
+    if (work < nwork) step(work, regs0);
 #ifdef WG_TIMING
     if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_wg_timing[k], (unsigned long long)tacc_[k]);
 #endif
