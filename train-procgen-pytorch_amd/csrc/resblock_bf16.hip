@@ -453,6 +453,166 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
     }
 }
 
+// ---- 32 channels @16x16, update-sized batches: the two residual blocks as two wave ROLES, pipelined over images (round 3).
+// resblock_pair_bf16_kernel keeps its four filter banks in LDS (78 KB) and, with two pixel tiles per wave, reads a bank fragment from
+// LDS for every two MFMAs: 1 KB of LDS traffic per MFMA, the LDS pipe 0.66 busy, the matrix pipe 0.40 (187 us per 8192 images).  Here
+// waves 0-3 run res1 of image k + 1 while waves 4-7 run res2 of image k, each role with ITS two banks in registers (36 fragments, loaded
+// once per launch): no bank reads at all, four pixel tiles per wave and conv, and the LDS holds five 16x16x32 tiles instead -- res1's
+// input, relu(res1.conv1), res1's output twice (the hand-over between the roles, double-buffered), relu(res2.conv1).  Two barriers per
+// image (after the staging, between the two convs), shared by the roles.  Arithmetic per output element as before (same banks, same K
+// order, same rounding points): the four stored tensors are bit-identical.
+struct RbPair32R {
+    static constexpr int C = 32, HW = 16, P = HW + 2, S = RB_S32, T_ELEMS = P * P * S, WS = 9 * 32 + 16, NMT = HW * HW / 16;
+    static constexpr size_t LDS_BYTES = (size_t)5 * T_ELEMS * 2;
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+};
+__global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockPairArgs a) {
+    using C = RbPair32R;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* s_x = smem_h;                         // res1 input (raw: ReLU on the operand reads, the skip connection reads it as is)
+    unsigned short* s_a1 = s_x + C::T_ELEMS;              // relu(res1.conv1 output)
+    unsigned short* s_h = s_a1 + C::T_ELEMS;              // res1 output (raw) [2]: written by role A for image k, read by role B one step later
+    unsigned short* s_a2 = s_h + 2 * C::T_ELEMS;          // relu(res2.conv1 output)
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool role_a = wv < 4;
+    const int rw = wv & 3;
+    for (int e = tid; e < 5 * C::T_ELEMS / 8; e += 512) ((uint4*)smem_h)[e] = (uint4){0u, 0u, 0u, 0u};      // halos stay zero
+    // this role's two banks: st[2m + nb] = (tap m, output block nb) of its conv1, st[18 + 2m + nb] of its conv2; its two bias quads per output block
+    f32x4 st[36];
+    f32x4 bq[2][2];
+    {
+        const unsigned short* bk1 = a.bank[role_a ? 0 : 2];
+        const unsigned short* bk2 = a.bank[role_a ? 1 : 3];
+        const float* b1 = a.b[role_a ? 0 : 2];
+        const float* b2 = a.b[role_a ? 1 : 3];
+#pragma unroll
+        for (int m = 0; m < 9; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                st[2 * m + nb] = __builtin_bit_cast(f32x4, *(const uint4*)(bk1 + (nb * 16 + i) * C::WS + m * 32 + kq * 8));
+                st[18 + 2 * m + nb] = __builtin_bit_cast(f32x4, *(const uint4*)(bk2 + (nb * 16 + i) * C::WS + m * 32 + kq * 8));
+            }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) { bq[0][nb] = *(const f32x4*)(b1 + nb * 16 + kq * 4); bq[1][nb] = *(const f32x4*)(b2 + nb * 16 + kq * 4); }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+    auto koffc = [](int m) { return ((m / 3) * C::P + (m % 3)) * C::S; };
+    constexpr int CENTER = (C::P + 1) * C::S;
+    // images of this workgroup: blockIdx.x, + gridDim.x, ...; role A works on image `step`, role B on image `step - 1`
+    const int nimg = ((int)blockIdx.x < a.n) ? (a.n - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    typedef unsigned rp_u32x4 __attribute__((ext_vector_type(4)));
+    rp_u32x4 rx[4];                                       // role A: the next image's input, 4 words per thread (16 x 16 pixels x 4 chunks / 256 threads)
+    auto load = [&](int k) {
+        const long long img = blockIdx.x + (long long)(k < nimg ? k : nimg - 1) * gridDim.x;       // past the end: the last image again (unconditional loads)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rx[q] = *(const rp_u32x4*)(a.x + img * (C::HW * C::HW * C::C) + (size_t)(tid + q * 256) * 8);
+    };
+    // one 3x3 conv of this role for TWO pixel tiles at once (four independent accumulator chains, ten operand reads in flight): operands
+    // from s_src (ReLU on read if relu), bank fragments st[b0 ..]
+    auto conv_tiles = [&](const unsigned short* s_src, const int (&org)[2], const int b0, bool relu, f32x4 (&acc)[2][2]) {
+        bf16x8 av[2][5];
+        auto rd = [&](int q, int m) {
+            bf16x8 v = *(const bf16x8*)(s_src + org[q] + kq * 8 + koffc(m));
+            if (relu) { const uint4 u = __builtin_bit_cast(uint4, v); v = __builtin_bit_cast(bf16x8, (uint4){rb_relu2_max(u.x), rb_relu2_max(u.y), rb_relu2_max(u.z), rb_relu2_max(u.w)}); }
+            return v;
+        };
+#pragma unroll
+        for (int m = 0; m < 5; ++m) { av[0][m] = rd(0, m); av[1][m] = rd(1, m); }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bf16x8 cur = av[q][m % 5];
+                acc[q][0] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[b0 + 2 * m]), cur, acc[q][0]);
+                acc[q][1] = MFMA_BF16(__builtin_bit_cast(bf16x8, st[b0 + 2 * m + 1]), cur, acc[q][1]);
+            }
+            if (m < 4) { av[0][m] = rd(0, m + 5); av[1][m] = rd(1, m + 5); }
+        }
+    };
+    if (role_a && nimg > 0) load(0);
+    for (int step = 0; step <= nimg; ++step) {
+        const bool on = role_a ? step < nimg : step >= 1;                   // (wave-uniform) this role has an image in this step
+        const int k = role_a ? step : step - 1;
+        const long long base = (blockIdx.x + (long long)(k < 0 ? 0 : k) * gridDim.x) * (C::HW * C::HW * C::C);
+        unsigned short* s_in = role_a ? s_x : s_h + ((step - 1) & 1) * C::T_ELEMS;      // the role's block input
+        unsigned short* s_mid = role_a ? s_a1 : s_a2;
+        unsigned short* a_out = role_a ? a.a1_out : a.a2_out;
+        unsigned short* y_out = role_a ? a.y1_out : a.y2_out;
+        __syncthreads();                                                    // everyone is done with the previous step's tiles
+        if (role_a && on) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + q * 256, pl = e >> 2;
+                *(rp_u32x4*)(s_x + ((pl >> 4) * C::P + (pl & 15)) * C::S + CENTER + (e & 3) * 8) = rx[q];
+            }
+            load(step + 1);
+        }
+        __syncthreads();
+        if (on) {
+            // ---- conv1 (+ bias) -> a (HBM) and relu(a) -> s_mid: tiles (rw, rw + 4), then (rw + 8, rw + 12)
+            for (int t = rw; t < C::NMT; t += 8) {
+                int pl[2], org[2];
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) { pl[q2] = (t + 4 * q2) * 16 + i; org[q2] = ((pl[q2] >> 4) * C::P + (pl[q2] & 15)) * C::S; }
+                f32x4 acc[2][2];
+                conv_tiles(s_in, org, 0, true, acc);
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[q2][nb][r] + bq[0][nb][r];
+                        const uint2 raw = rb_pack(v);
+                        if (a_out) *(uint2*)(a_out + base + (long long)pl[q2] * C::C + nb * 16 + kq * 4) = raw;
+                        *(uint2*)(s_mid + org[q2] + CENTER + nb * 16 + kq * 4) = (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};
+                    }
+            }
+        }
+        __syncthreads();
+        if (on) {
+            // ---- conv2 (+ bias) + skip -> y (HBM); role A also hands it to role B through s_h[step & 1]
+            unsigned short* s_nxt = s_h + (step & 1) * C::T_ELEMS;
+            for (int t = rw; t < C::NMT; t += 8) {
+                int pl[2], org[2];
+                uint2 sk[2][2];
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    pl[q2] = (t + 4 * q2) * 16 + i; org[q2] = ((pl[q2] >> 4) * C::P + (pl[q2] & 15)) * C::S;
+                    sk[q2][0] = *(const uint2*)(s_in + org[q2] + CENTER + kq * 4); sk[q2][1] = *(const uint2*)(s_in + org[q2] + CENTER + 16 + kq * 4);
+                }
+                f32x4 acc[2][2];
+                conv_tiles(s_mid, org, 18, false, acc);
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[q2][nb][r] + bq[1][nb][r] + rb_lane(sk[q2][nb], r);
+                        const uint2 raw = rb_pack(v);
+                        if (y_out) *(uint2*)(y_out + base + (long long)pl[q2] * C::C + nb * 16 + kq * 4) = raw;
+                        if (role_a) *(uint2*)(s_nxt + org[q2] + CENTER + nb * 16 + kq * 4) = raw;
+                    }
+            }
+        }
+    }
+}
+#ifndef RB32_PAIR_ROLES
+#define RB32_PAIR_ROLES 1          // 32 channels @16x16, n >= 1024: 1 = resblock_pair32r_bf16_kernel, 0 = resblock_pair_bf16_kernel<RB_32_16>
+#endif
+static void launch_rbp32r(const ResblockPairArgs& a, hipStream_t st) {
+    static std::once_flag attr;
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_pair32r_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbPair32R::LDS_BYTES); });
+    const int grid = a.n > 256 ? 256 : a.n;
+    if (grid < 1) return;
+    hipLaunchKernelGGL(resblock_pair32r_bf16_kernel, dim3(grid), dim3(512), RbPair32R::LDS_BYTES, st, a);
+}
+
 template <class C>
 static void launch_rbp_t(const ResblockPairArgs& a, hipStream_t st) {
     constexpr size_t LDS = (size_t)(C::X_ELEMS + C::Y_ELEMS + 4 * C::W_ELEMS) * 2 + 4 * C::C * 4;
@@ -2256,7 +2416,7 @@ void launch_resblock_pair_bf16(ConvShape s, const void* x, const float* const* b
                        (unsigned short*)y2_out, n, {bank[0], bank[1], bank[2], bank[3]}};
     switch (s) {
         case CS_16_16_32: launch_rbp_t<RB_16_32>(a, st); break;
-        case CS_32_32_16: launch_rbp_t<RB_32_16>(a, st); break;
+        case CS_32_32_16: if (RB32_PAIR_ROLES && n >= 1024) launch_rbp32r(a, st); else launch_rbp_t<RB_32_16>(a, st); break;
         case CS_32_32_8:  if (n <= 1024) launch_rbp_t<RB_32_8S>(a, st); else launch_rbp_t<RB_32_8P>(a, st); break;
         default: break;
     }
