@@ -186,7 +186,13 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_roll_bf16_kernel(ConvArg
     unsigned short* s_c = s_w + C::W_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
     const unsigned short* g_in = (const unsigned short*)a.in;
-    for (int e = tid; e < C::W_ELEMS / 8; e += 256) ((uint4*)s_w)[e] = ((const uint4*)a.wbank)[e];
+    // the filter bank lives in REGISTERS (10 / 18 fragments per lane, loaded once per launch): a third / half of the conv phase's LDS reads were
+    // bank fragments, re-read for every K step of every step of every image
+    bf16x8 breg[C::NK][C::NB];
+#pragma unroll
+    for (int m = 0; m < C::NK; ++m)
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb) breg[m][nb] = *(const bf16x8*)(a.wbank + (nb * 16 + i) * C::WS + m * 32 + kq * 8);
     for (int e = tid; e < R::IN_ELEMS / 8; e += 256) ((uint4*)s_in)[e] = (uint4){0u, 0u, 0u, 0u};          // column halos stay zero
     for (int e = tid; e < C::CR * (C::COUT / 2); e += 256) ((unsigned*)s_c)[(e / (C::COUT / 2)) * (C::HW + 1) * (C::SCS / 2) + e % (C::COUT / 2)] = MI_KEY_MIN2;
     float bias_r[C::NB][4];
@@ -247,18 +253,15 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_roll_bf16_kernel(ConvArg
         for (int mt = 0; mt < R::MT; ++mt)
 #pragma unroll
             for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int bbase = i * C::WS + kq * 8;
 #pragma unroll
         for (int m = 0; m < C::NK; ++m) {
-            bf16x8 av[R::MT], bv[C::NB];
+            bf16x8 av[R::MT];
 #pragma unroll
             for (int mt = 0; mt < R::MT; ++mt) av[mt] = *(const bf16x8*)(s_in + abase[mt] + koff[m]);
 #pragma unroll
-            for (int nb = 0; nb < C::NB; ++nb) bv[nb] = *(const bf16x8*)(s_w + bbase + nb * 16 * C::WS + m * 32);
-#pragma unroll
             for (int mt = 0; mt < R::MT; ++mt)
 #pragma unroll
-                for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(bv[nb], av[mt], acc[mt][nb]);
+                for (int nb = 0; nb < C::NB; ++nb) acc[mt][nb] = MFMA_BF16(breg[m][nb], av[mt], acc[mt][nb]);
         }
 #pragma unroll
         for (int mt = 0; mt < R::MT; ++mt)
