@@ -1,13 +1,20 @@
 // Micro-bench of the residual-pair forward at 32 channels @16x16 (training: all four outputs stored): the LDS-bank kernel against the
 // role-pipelined one, with checksums of all four outputs (they must agree bit for bit):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I train-procgen-pytorch_amd/csrc scratch/kbench_pair32.hip -o scratch/kb_pair32 ; ./kb_pair32 [n]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DPAIR_HW=8] -I train-procgen-pytorch_amd/csrc scratch/kbench_pair32.hip -o scratch/kb_pair32 ; ./kb_pair32 [n]
 #include "resblock_bf16.hip"
 #include <cstdio>
 #include <vector>
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 8192, reps = 10;
-    using C = RB_32_16;
-    const size_t X = (size_t)n * 16 * 16 * 32;
+#ifndef PAIR_HW
+#define PAIR_HW 16
+#endif
+#if PAIR_HW == 16
+    using C = RB_32_16; using R = RBR_32_16;
+#else
+    using C = RB_32_8P; using R = RBR_32_8;
+#endif
+    const size_t X = (size_t)n * PAIR_HW * PAIR_HW * 32;
     unsigned short *x, *o[4], *banks; float* bias;
     hipMalloc(&x, X * 2 + 4096); for (auto& q : o) hipMalloc(&q, X * 2 + 4096);
     hipMalloc(&banks, (size_t)4 * C::W_ELEMS * 2 + 4096); hipMalloc(&bias, 4 * 32 * 4);
@@ -22,7 +29,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 4; ++k) { a.b[k] = bias + 32 * k; a.bank[k] = banks + (size_t)k * C::W_ELEMS; }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 2; ++mode) {
-        auto run = [&]() { if (mode) launch_rbp32r(a, 0); else launch_rbp_t<C>(a, 0); };
+        auto run = [&]() { if (mode) launch_rbp32r<R>(a, 0); else launch_rbp_t<C>(a, 0); };
         for (auto& q : o) hipMemset(q, 0, X * 2);
         for (int k = 0; k < 3; ++k) run();
         hipEventRecord(e0, 0);

@@ -461,13 +461,17 @@ __global__ __launch_bounds__(C::NT) void resblock_pair_bf16_kernel(ResblockPairA
 // input, relu(res1.conv1), res1's output twice (the hand-over between the roles, double-buffered), relu(res2.conv1).  Two barriers per
 // image (after the staging, between the two convs), shared by the roles.  Arithmetic per output element as before (same banks, same K
 // order, same rounding points): the four stored tensors are bit-identical.
-struct RbPair32R {
-    static constexpr int C = 32, HW = 16, P = HW + 2, S = RB_S32, T_ELEMS = P * P * S, WS = 9 * 32 + 16, NMT = HW * HW / 16;
+template <int HW_, int NIMG_>
+struct RbPair32R {                                       // HW 16: one image per step; HW 8: two images per step (8 pixel tiles: two per wave and conv)
+    static constexpr int C = 32, HW = HW_, NIMG = NIMG_, P = HW + 2, S = RB_S32, IMG_ELEMS = P * P * S, T_ELEMS = NIMG * IMG_ELEMS, WS = 9 * 32 + 16;
+    static constexpr int NPX = NIMG * HW * HW, NMT = NPX / 16, NWORD = NPX * 4 / 256;       // pixels, pixel tiles, staged 16-byte words per thread of role A
     static constexpr size_t LDS_BYTES = (size_t)5 * T_ELEMS * 2;
-    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+    static_assert(LDS_BYTES <= 160 * 1024 && NMT % 8 == 0 && NPX * 4 % 256 == 0, "one workgroup per CU; tile pairs per wave; whole staging words");
+    // pixel pl of the step -> element offset of its window origin in a tile set
+    static __device__ __forceinline__ int org(int pl) { return (pl / (HW * HW)) * IMG_ELEMS + (((pl / HW) % HW) * P + pl % HW) * S; }
 };
+template <class C>
 __global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockPairArgs a) {
-    using C = RbPair32R;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* s_x = smem_h;                         // res1 input (raw: ReLU on the operand reads, the skip connection reads it as is)
     unsigned short* s_a1 = s_x + C::T_ELEMS;              // relu(res1.conv1 output)
@@ -499,14 +503,22 @@ __global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockP
     __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
     auto koffc = [](int m) { return ((m / 3) * C::P + (m % 3)) * C::S; };
     constexpr int CENTER = (C::P + 1) * C::S;
-    // images of this workgroup: blockIdx.x, + gridDim.x, ...; role A works on image `step`, role B on image `step - 1`
-    const int nimg = ((int)blockIdx.x < a.n) ? (a.n - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    // items (NIMG images) of this workgroup: blockIdx.x, + gridDim.x, ...; role A works on item `step`, role B on item `step - 1`
+    const int nitem = (a.n + C::NIMG - 1) / C::NIMG;
+    const int nimg = ((int)blockIdx.x < nitem) ? (nitem - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     typedef unsigned rp_u32x4 __attribute__((ext_vector_type(4)));
-    rp_u32x4 rx[4];                                       // role A: the next image's input, 4 words per thread (16 x 16 pixels x 4 chunks / 256 threads)
+    rp_u32x4 rx[C::NWORD];                                // role A: the next item's input (pixels x 4 chunks / 256 threads words per thread)
     auto load = [&](int k) {
-        const long long img = blockIdx.x + (long long)(k < nimg ? k : nimg - 1) * gridDim.x;       // past the end: the last image again (unconditional loads)
+        const long long it = blockIdx.x + (long long)(k < nimg ? k : nimg - 1) * gridDim.x;        // past the end: the last item again (unconditional loads)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rx[q] = *(const rp_u32x4*)(a.x + img * (C::HW * C::HW * C::C) + (size_t)(tid + q * 256) * 8);
+        for (int q = 0; q < C::NWORD; ++q) {
+            if constexpr (C::NIMG == 1) rx[q] = *(const rp_u32x4*)(a.x + it * (C::HW * C::HW * C::C) + (size_t)(tid + q * 256) * 8);
+            else {
+                const int e = tid + q * 256, pl = e >> 2;
+                long long n = it * C::NIMG + pl / (C::HW * C::HW); n = n < a.n ? n : a.n - 1;      // an image past the end: a valid one (its outputs are not stored)
+                rx[q] = *(const rp_u32x4*)(a.x + (n * (C::HW * C::HW) + pl % (C::HW * C::HW)) * C::C + (e & 3) * 8);
+            }
+        }
     };
     // one 3x3 conv of this role for TWO pixel tiles at once (four independent accumulator chains, ten operand reads in flight): operands
     // from s_src (ReLU on read if relu), bank fragments st[b0 ..]
@@ -537,7 +549,9 @@ __global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockP
     for (int step = 0; step <= nimg; ++step) {
         const bool on = role_a ? step < nimg : step >= 1;                   // (wave-uniform) this role has an image in this step
         const int k = role_a ? step : step - 1;
-        const long long base = (blockIdx.x + (long long)(k < 0 ? 0 : k) * gridDim.x) * (C::HW * C::HW * C::C);
+        const long long item0 = (blockIdx.x + (long long)(k < 0 ? 0 : k) * gridDim.x) * C::NIMG;       // first image of the role's item
+        const long long base = item0 * (C::HW * C::HW * C::C);
+        const int left = a.n - (int)item0;                                  // images of the item that exist
         unsigned short* s_in = role_a ? s_x : s_h + ((step - 1) & 1) * C::T_ELEMS;      // the role's block input
         unsigned short* s_mid = role_a ? s_a1 : s_a2;
         unsigned short* a_out = role_a ? a.a1_out : a.a2_out;
@@ -545,9 +559,9 @@ __global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockP
         __syncthreads();                                                    // everyone is done with the previous step's tiles
         if (role_a && on) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < C::NWORD; ++q) {
                 const int e = tid + q * 256, pl = e >> 2;
-                *(rp_u32x4*)(s_x + ((pl >> 4) * C::P + (pl & 15)) * C::S + CENTER + (e & 3) * 8) = rx[q];
+                *(rp_u32x4*)(s_x + C::org(pl) + CENTER + (e & 3) * 8) = rx[q];
             }
             load(step + 1);
         }
@@ -557,7 +571,7 @@ __global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockP
             for (int t = rw; t < C::NMT; t += 8) {
                 int pl[2], org[2];
 #pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) { pl[q2] = (t + 4 * q2) * 16 + i; org[q2] = ((pl[q2] >> 4) * C::P + (pl[q2] & 15)) * C::S; }
+                for (int q2 = 0; q2 < 2; ++q2) { pl[q2] = (t + 4 * q2) * 16 + i; org[q2] = C::org(pl[q2]); }
                 f32x4 acc[2][2];
                 conv_tiles(s_in, org, 0, true, acc);
 #pragma unroll
@@ -568,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockP
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = acc[q2][nb][r] + bq[0][nb][r];
                         const uint2 raw = rb_pack(v);
-                        if (a_out) *(uint2*)(a_out + base + (long long)pl[q2] * C::C + nb * 16 + kq * 4) = raw;
+                        if (a_out && (C::NIMG == 1 || pl[q2] / (C::HW * C::HW) < left)) *(uint2*)(a_out + base + (long long)pl[q2] * C::C + nb * 16 + kq * 4) = raw;
                         *(uint2*)(s_mid + org[q2] + CENTER + nb * 16 + kq * 4) = (uint2){rb_relu2(raw.x), rb_relu2(raw.y)};
                     }
             }
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockP
                 uint2 sk[2][2];
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
-                    pl[q2] = (t + 4 * q2) * 16 + i; org[q2] = ((pl[q2] >> 4) * C::P + (pl[q2] & 15)) * C::S;
+                    pl[q2] = (t + 4 * q2) * 16 + i; org[q2] = C::org(pl[q2]);
                     sk[q2][0] = *(const uint2*)(s_in + org[q2] + CENTER + kq * 4); sk[q2][1] = *(const uint2*)(s_in + org[q2] + CENTER + 16 + kq * 4);
                 }
                 f32x4 acc[2][2];
@@ -595,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockP
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = acc[q2][nb][r] + bq[1][nb][r] + rb_lane(sk[q2][nb], r);
                         const uint2 raw = rb_pack(v);
-                        if (y_out) *(uint2*)(y_out + base + (long long)pl[q2] * C::C + nb * 16 + kq * 4) = raw;
+                        if (y_out && (C::NIMG == 1 || pl[q2] / (C::HW * C::HW) < left)) *(uint2*)(y_out + base + (long long)pl[q2] * C::C + nb * 16 + kq * 4) = raw;
                         if (role_a) *(uint2*)(s_nxt + org[q2] + CENTER + nb * 16 + kq * 4) = raw;
                     }
             }
@@ -603,15 +617,18 @@ __global__ __launch_bounds__(512, 2) void resblock_pair32r_bf16_kernel(ResblockP
     }
 }
 #ifndef RB32_PAIR_ROLES
-#define RB32_PAIR_ROLES 1          // 32 channels @16x16, n >= 1024: 1 = resblock_pair32r_bf16_kernel, 0 = resblock_pair_bf16_kernel<RB_32_16>
+#define RB32_PAIR_ROLES 1          // bit 0: 32 channels @16x16 (n >= 1024), bit 1: @8x8 (n > 1024; two images per step: 55.4 against 56.1 us, not taken) run resblock_pair32r_bf16_kernel instead of resblock_pair_bf16_kernel
 #endif
+template <class C>
 static void launch_rbp32r(const ResblockPairArgs& a, hipStream_t st) {
     static std::once_flag attr;
-    std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_pair32r_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbPair32R::LDS_BYTES); });
-    const int grid = a.n > 256 ? 256 : a.n;
+    std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_pair32r_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES); });
+    const int items = (a.n + C::NIMG - 1) / C::NIMG, grid = items > 256 ? 256 : items;
     if (grid < 1) return;
-    hipLaunchKernelGGL(resblock_pair32r_bf16_kernel, dim3(grid), dim3(512), RbPair32R::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(resblock_pair32r_bf16_kernel<C>, dim3(grid), dim3(512), C::LDS_BYTES, st, a);
 }
+using RBR_32_16 = RbPair32R<16, 1>;
+using RBR_32_8 = RbPair32R<8, 2>;
 
 template <class C>
 static void launch_rbp_t(const ResblockPairArgs& a, hipStream_t st) {
@@ -2416,8 +2433,8 @@ void launch_resblock_pair_bf16(ConvShape s, const void* x, const float* const* b
                        (unsigned short*)y2_out, n, {bank[0], bank[1], bank[2], bank[3]}};
     switch (s) {
         case CS_16_16_32: launch_rbp_t<RB_16_32>(a, st); break;
-        case CS_32_32_16: if (RB32_PAIR_ROLES && n >= 1024) launch_rbp32r(a, st); else launch_rbp_t<RB_32_16>(a, st); break;
-        case CS_32_32_8:  if (n <= 1024) launch_rbp_t<RB_32_8S>(a, st); else launch_rbp_t<RB_32_8P>(a, st); break;
+        case CS_32_32_16: if (RB32_PAIR_ROLES && n >= 1024) launch_rbp32r<RBR_32_16>(a, st); else launch_rbp_t<RB_32_16>(a, st); break;
+        case CS_32_32_8:  if (n <= 1024) launch_rbp_t<RB_32_8S>(a, st); else if (RB32_PAIR_ROLES & 2) launch_rbp32r<RBR_32_8>(a, st); else launch_rbp_t<RB_32_8P>(a, st); break;
         default: break;
     }
 }
