@@ -1614,9 +1614,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_bf16_kernel(WgradArgs a, cons
 //     pixel(window, position rq | 4 + rq) + tap(4 m + cp); the 16 columns of MFMA m are 4 taps x (3 channels + the 1.0 that sums the bias);
 //   * two LDS tile sets and two staging register sets: item k + 1 is stored while item k is multiplied, loads run two items ahead,
 //     one barrier per item.
-#ifndef C1H_EXP
-#define C1H_EXP 0
-#endif
 #ifndef C1H_TWAVE
 #define C1H_TWAVE 0
 #endif
@@ -1667,7 +1664,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_onehot_bf16_kernel(WgradArgs 
     };
     auto store = [&](const Stage& S, unsigned char* set, int w) {
         const int oy0 = (w % C1H::TPI) * C1H::R;
-        if (ftid < C1H::NTASK && C1H_EXP != 5) {
+        if (ftid < C1H::NTASK) {
             unsigned short* s_in = (unsigned short*)set;
             const int row = ftid >> 4, gy = 2 * oy0 - 2 + row;
             const bool in = gy >= 0 && gy < 64;
@@ -1711,9 +1708,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_onehot_bf16_kernel(WgradArgs 
             F.g16 = *(const unsigned short*)(set + offG + s * 128); F.ab = *(const unsigned char*)(set + offA + s * 64);
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-#if C1H_EXP == 3          // timing experiment: two of the six B reads
-                if (m > 0) { F.lo[m] = F.lo[0]; F.hi[m] = F.hi[0]; continue; }
-#endif
                 F.lo[m] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(set + offB[0][m] + s * 64));
                 F.hi[m] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(set + offB[1][m] + s * 64));
             }
@@ -1730,22 +1724,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad_onehot_bf16_kernel(WgradArgs 
     auto mul = [&](const Frag& F, int s) {
         bf16x8 av;
         if (s < 8) {                                            // slot j of the lane's 8 = position j: g goes to slot arg
-#if C1H_EXP == 1          // timing experiment: no one-hot placement
-            const c1h_u32x4 aw = {F.g16, F.ab, F.g16, F.ab};
-#else
             const unsigned val = F.g16 << ((F.ab & 1u) * 16u), d = F.ab >> 1;
             const c1h_u32x4 aw = {d == 0u ? val : 0u, d == 1u ? val : 0u, d == 2u ? val : 0u, d == 3u ? val : 0u};
-#endif
             av = __builtin_bit_cast(bf16x8, aw);
         } else
             av = __builtin_shufflevector(F.alo, F.ahi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-#if C1H_EXP == 2          // timing experiment: one MFMA instead of three
-        for (int m = 0; m < 1; ++m) { const bf16x8 bv = __builtin_shufflevector(F.lo[m], F.hi[m], 0, 1, 2, 3, 4, 5, 6, 7) ^ __builtin_shufflevector(F.lo[1], F.hi[1], 0, 1, 2, 3, 4, 5, 6, 7) ^ __builtin_shufflevector(F.lo[2], F.hi[2], 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[m] = MFMA_BF16(av, bv, acc[m]); }
-#else
         for (int m = 0; m < 3; ++m) acc[m] = MFMA_BF16(av, __builtin_shufflevector(F.lo[m], F.hi[m], 0, 1, 2, 3, 4, 5, 6, 7), acc[m]);
-#endif
     };
     auto compute = [&](const unsigned char* set) {
         Frag F0, F1;
@@ -1788,9 +1773,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_onehot_bf16_kernel(WgradArgs 
             load(S, w3, frame);
         }
         TCKH(2);
-#if C1H_EXP != 4
         compute(set_cur);
-#endif
         TCKH(3);
         __syncthreads();
     };
