@@ -1700,8 +1700,9 @@ struct RbFull32T {                               // HW 16: 8-row tiles, 512 thre
 };
 using RbFull32 = RbFull32T<16, 512>;
 #ifndef RB32S_TH
-#define RB32S_TH 8           // rows per item of the wave-specialised kernel (16 = whole image: 128 KB of LDS now that no bank sits there)
-#endif
+#define RB32S_TH 16          // rows per item of the wave-specialised kernel: 16 = whole image (128 KB of LDS now that no bank sits there): no halo rows re-read or
+#endif                       // recomputed, three barriers per image instead of six.  It needs the weight-gradient step loops unrolled by 4, not 8 (spills: 1007 us);
+                             // micro-bench per 8192 images: 8-row items 220-222 us, 16-row items 203 (step loops rolled / by 2: 206-212)
 using RbFull32W = RbFull32T<16, 512, RB32S_TH>;
 using RbFull32S = RbFull32T<8, 256>;
 
@@ -2069,7 +2070,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full32s_bf16_kernel(RbFul
             }
         } else {
             // ---- conv2's weight / bias gradient from (dy, relu(a)): needs nothing the conv waves are producing
-#pragma unroll
+#pragma unroll 4                                             // (16-row items have 8 steps: unrolled by 8 the kernel spills -- hoisted operand addresses)
             for (int t = 0; t < C::NSTEP; ++t) wg_step(t, s_x, (2 * C::P + 1) * C::S, s_a, 0, rw == 2);
         }
         RTCK(1);                                            // phase-1 work
@@ -2106,7 +2107,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bwd_full32s_bf16_kernel(RbFul
             }
         } else {
             // ---- conv1's weight / bias gradient from (da, relu(x))
-#pragma unroll
+#pragma unroll 4
             for (int t = 0; t < C::NSTEP; ++t) wg_step(t, s_y, (C::P + 1) * C::S, s_p, 10, rw == 3);
         }
     }
