@@ -4,8 +4,8 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3_prof -o runc -- python3 $R/bench.py --no-cpu-baseline --no-fp32-record --steps 3 --warmup 1 > $O/r03_run8_bf16_bench_under_rocprof.json 2> $O/r3_prof.err || exit 1
-cp $(find $O/r3_prof -name '*kernel_stats.csv' | head -1) $O/r03_run8_bf16_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3_prof -o runc -- python3 $R/bench.py --no-cpu-baseline --no-fp32-record --steps 3 --warmup 1 > $O/r03_run9_bf16_bench_under_rocprof.json 2> $O/r3_prof.err || exit 1
+cp $(find $O/r3_prof -name '*kernel_stats.csv' | head -1) $O/r03_run9_bf16_kernel_stats.csv
 rm -rf $O/r3_prof
 W="python3 $R/scratch/pmc_workload.py 2 bf16"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $O/r3_pmc_sq -o runc -- $W > $O/r3_pmc_sq.log 2>&1 || exit 2
