@@ -194,6 +194,19 @@ def test_residual_pair_kernel_equals_two_single_launches(eng, ch, hw, n):
     assert np.array_equal(pa, a2) and np.array_equal(py, y2)
 
 
+def test_residual_pair_role_pipelined_kernel_equals_the_lds_bank_kernel(eng):
+    """32 channels @16x16: launches of >= 1024 images run res1 and res2 as two wave roles pipelined over images, each role's filter banks
+    in registers (resblock_pair32r_bf16_kernel); smaller launches keep the four banks in LDS (resblock_pair_bf16_kernel).  Same arithmetic
+    per output element: 1030 images in one launch == the same images in two launches of 515, bit for bit (res2.conv1 output and block output)."""
+    g = torch.Generator().manual_seed(811)
+    w1, w2 = torch.randn(32, 32, 3, 3, generator=g) * 0.1, torch.randn(32, 32, 3, 3, generator=g) * 0.1
+    b1, b2 = torch.randn(32, generator=g), torch.randn(32, generator=g)
+    x = nhwc(r16(torch.randn(1030, 32, 16, 16, generator=g)))
+    pa, py = eng.op_resblock(3, x, w1.numpy(), w2.numpy(), b1=b1.numpy(), b2=b2.numpy())
+    halves = [eng.op_resblock(3, x[k:k + 515], w1.numpy(), w2.numpy(), b1=b1.numpy(), b2=b2.numpy()) for k in (0, 515)]
+    assert np.array_equal(pa, np.concatenate([h[0] for h in halves])) and np.array_equal(py, np.concatenate([h[1] for h in halves]))
+
+
 @pytest.mark.parametrize("ch,hw", [(16, 32), (32, 16), (32, 8)])
 @pytest.mark.parametrize("n", [1, 7])
 def test_residual_block_whole_backward_bf16(eng, ch, hw, n):
