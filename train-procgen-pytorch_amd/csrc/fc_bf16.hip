@@ -480,13 +480,15 @@ __global__ __launch_bounds__(256) void fc_small_bf16_kernel(const unsigned short
     const int env = e0 + i;
     const unsigned short* xa = X + (long long)(env < n ? env : n - 1) * 2048 + wave * 512 + kq * 8;
     const unsigned short* wb = Wp + (long long)(o0 + i) * 2048 + wave * 512 + kq * 8;
-    uint4 ra[16], rb[16];
+    typedef unsigned fs_u32x4 __attribute__((ext_vector_type(4)));
+    fs_u32x4 ra[16], rb[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) { ra[s] = *(const uint4*)(xa + s * 32); rb[s] = *(const uint4*)(wb + s * 32); }
+    for (int s = 0; s < 16; ++s) { ra[s] = *(const fs_u32x4*)(xa + s * 32); rb[s] = *(const fs_u32x4*)(wb + s * 32); }
+    __builtin_amdgcn_sched_barrier(0);                     // (the scheduler otherwise sinks the loads between the MFMAs: 4 round trips instead of 1)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        const uint4 a = {fc_relu2(ra[s].x), fc_relu2(ra[s].y), fc_relu2(ra[s].z), fc_relu2(ra[s].w)};
+        const fs_u32x4 a = {fc_relu2(ra[s].x), fc_relu2(ra[s].y), fc_relu2(ra[s].z), fc_relu2(ra[s].w)};
         acc = MFMA_BF16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, rb[s]), acc);
     }
 #pragma unroll
