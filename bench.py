@@ -228,7 +228,7 @@ def main():
                     "gradient / statistics all-reduce, barriers) with every rank on GPU 0 and the gloo backend; the number it prints is not a result")
     ap.add_argument("--no-merge", action="store_true", help="diagnostic (with --rank-share R): the R accumulated passes of a minibatch run one by one "
                     "instead of merged into one pass -- what splitting a minibatch into cache-sized pieces would cost / gain")
-    ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic: mi_debug_flags bits (1: unfused rollout tail, 4: frames always uploaded by DMA copy, never pulled by a kernel)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic: mi_debug_flags bits (1: unfused rollout tail, 4: frames always uploaded by DMA copy, never pulled by a kernel, 16: no side stream in the minibatch pass)")
     ap.add_argument("--no-h2d", action="store_true", help="diagnostic: policy steps read frames already resident in HBM (no per-step upload); "
                     "the default uploads every step's E frames from pinned host memory inside the timed region, as the real loop must")
     ap.add_argument("--engine-only", action="store_true", help="diagnostic: the rollout phase drives mi_rollout_submit / mi_rollout_wait directly with frames "

@@ -249,7 +249,9 @@ int mi_debug_philox(mi_ctx* ctx, const uint32_t* ctr_key6, int32_t n, uint32_t* 
 int mi_debug_step_latency(mi_ctx* ctx, int32_t t, int32_t iters, int32_t mode, float* us_out);
 /* bit 0 set: rollout-sized bf16 inference passes use the separate block-2 / block-3 kernels instead of the fused launch
  * (rollout_bf16.hip) -- the A side of the bit-equality test of the two paths;
- * bit 2 set: a group's frames always go up by DMA copy, never pulled by a kernel (A/B timing) */
+ * bit 2 set: a group's frames always go up by DMA copy, never pulled by a kernel (A/B timing);
+ * bit 4 set: a minibatch pass keeps the logged statistics and embedder.fc's weight gradient on the main stream instead of
+ * forking them onto the side stream -- the A side of the bit-equality test of the two orders */
 int mi_debug_flags(mi_ctx* ctx, int32_t flags);
 
 #ifdef __cplusplus

@@ -449,6 +449,46 @@ def test_fc_bf16_matrix_core_path_matches_small_batch_path(T, B):
         assert rel < 1e-1, (k, rel)          # deepest layer measured 3.5e-2: bf16 rounding of d(feat) + of every dgrad output below it
 
 
+def test_side_stream_minibatch_equals_the_single_stream_pass():
+    """Update-sized bf16 minibatches without batch-level loss terms fork a side stream behind heads_bwd: the feature-sparsity metric,
+    the loss records and embedder.fc's weight / bias gradients run beside the rest of the backward pass and are joined in front of the
+    slab sums (engine.hip net_backward).  Same kernels on the same data in the same per-buffer order: loss records, gradients and the
+    parameters after three optimizer steps (two of them with accumulated half-minibatches: two forks before one optimizer step) are
+    BIT-identical to the single-stream pass (mi_debug_flags bit 4)."""
+    from mi355 import engine as M, layout
+    from mi355.engine import Engine
+    T, E, A, B = 32, 64, 15, 2048
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(T + 1, E, 64, 64, 3), dtype=np.uint8)
+    flat = layout.flatten(layout.impala_param_shapes(A), npz_params(load_npz("g3_impala_forward.npz")))
+    out = []
+    for flags in (0, 16):
+        eng = Engine("impala", T, E, A, B, precision="bf16")
+        eng.set_params(flat)
+        eng.debug_flags(flags)
+        for t in range(T + 1):
+            eng.put_obs(t, frames[t]); eng.sync()
+        r2 = np.random.default_rng(4)
+        eng.write_field(M.F_ACT, r2.integers(0, A, (T, E)).astype(np.float32))
+        eng.write_field(M.F_LOGP, (np.log(1 / A) + 0.3 * r2.standard_normal((T, E))).astype(np.float32))
+        eng.write_field(M.F_VALUE, (0.5 * r2.standard_normal((T + 1, E))).astype(np.float32))
+        eng.write_field(M.F_REW, r2.standard_normal((T, E)).astype(np.float32))
+        eng.write_field(M.F_DONE, (r2.random((T, E)) < 0.05).astype(np.float32))
+        eng.compute_estimates(0.999, 0.95, True, True)
+        idx = np.random.default_rng(5).permutation(T * E)
+        eng.minibatch(idx, B, eng.hparams())
+        g1 = eng.get_grads().copy()
+        eng.optimizer_step(5e-4, 0.5, 1)
+        for k in range(2):
+            eng.minibatch(idx[:B // 2], B, eng.hparams()); eng.minibatch(idx[B // 2:], B, eng.hparams())
+            eng.optimizer_step(5e-4, 0.5, 1)
+        out.append((g1, np.array(eng.loss_log()), eng.get_params().copy()))
+        eng.close()
+    assert np.abs(out[0][0]).max() > 0 and len(out[0][1]) == 5
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+
+
 def test_fc_small_batch_kernel_matches_tiled_kernel():
     """embedder.fc has two bf16 kernels: the 128x64-tiled one for update-sized batches and the latency-oriented one for
     rollout-sized batches (n < 1024: one 16x16 output tile per workgroup, K split over the 4 waves).  Same packed

@@ -165,6 +165,14 @@ struct mi_ctx {
     struct GroupWorker* gw[MAX_GROUPS];      // one host thread per group issues that group's copies + launches (a step is ~9 API calls = ~30 us of host time)
     std::atomic<int64_t> copy_slot_ns{0}; double copy_rate_bytes_per_us;      // uploads of the env groups take turns on the PCIe link (group_issue)
     std::unordered_map<const void*, bool> pull_ok; bool no_pull;      // frame buffers a kernel may read (mi_debug_flags bit 2: always DMA)
+    // Side stream of a minibatch pass: the logged statistics (feature-sparsity metric, loss records) and embedder.fc's weight / bias
+    // gradients are needed by nobody before the optimizer step, so they run beside the backward pass instead of in front of it
+    // (seven small launches + fc_tn: ~65 us of kernels per 2.7 ms minibatch, of which the update gets ~15 us back -- 64.6 -> 64.2 ms per
+    // iteration, same-box A/B by the debug flag: fc_tn and the column maxima are real work that now shares the machine with fc_dgrad).
+    // Fork after heads_bwd, join in front of the slab sums.
+    hipStream_t side_stream; hipEvent_t ev_side_fork, ev_side_join;
+    bool side_on;               // mi_debug_flags bit 4 clears it (A/B tests)
+    struct SideJob { bool armed; LossArgs a; SegTab st; float* ring; float* fsr; float* log; } side;
     bool rollout_tail;          // bf16 inference passes of <= 256 samples run blocks 2 + 3 as one launch (mi_debug_flags bit 0 clears it: A/B tests)
     float *fs_colmax, fs_grad_coef; int *fs_arg, fs_G;      // feature-sparsity gradient (fs_coef != 0): column maxima / first arg-max rows of the minibatch
     // ... on more than one rank (multirank mode 1): per-column candidates for the max-all-reduce (MI_PTR_FS_KEYS), this rank's own copy, and
@@ -319,6 +327,8 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
     c->es = c->bf ? 2.0 : 4.0;
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIPC(hipEventCreateWithFlags(&c->ev_side_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&c->ev_side_join, hipEventDisableTiming));
+    c->side_stream = nullptr; c->side_on = true; c->side.armed = false;
     if (cfg->arch == MI_ARCH_IMPALA) build_impala_layout(c); else build_mlp_layout(c);
     if (cfg->arch == MI_ARCH_IMPALA && !impala_regions_ok(c)) { delete c; return fail(-1, "internal: parameter layout does not split at embedder.fc.weight"); }
 
@@ -475,7 +485,7 @@ int mi_destroy(mi_ctx* c) {
     hipFree(c->s_act); hipFree(c->s_logp); hipFree(c->s_val);
     if (c->fc_wp) hipFree(c->fc_wp); if (c->fc_wt) hipFree(c->fc_wt);
     if (c->banks) hipFree(c->banks); if (c->d_bank_desc) hipFree(c->d_bank_desc); if (c->c1_bank) hipFree(c->c1_bank);
-    hipFree(c->stats_ring); hipFree(c->fs_ring); hipFree(c->fs_parts); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd); hipFree(c->d_done_ctr); hipHostFree(c->h_flag);
+    hipFree(c->stats_ring); hipFree(c->fs_ring); hipFree(c->fs_parts); if (c->d_slab_desc) hipFree(c->d_slab_desc); if (c->sal_dc) hipFree(c->sal_dc); if (c->sal_dx) hipFree(c->sal_dx); hipFree(c->d_pack); hipFree(c->d_rd); hipHostFree(c->h_pack); hipHostFree(c->h_rd); hipFree(c->d_done_ctr); if (c->side_stream) hipStreamDestroy(c->side_stream); hipEventDestroy(c->ev_side_fork); hipEventDestroy(c->ev_side_join); hipHostFree(c->h_flag);
     { float* gr[] = {c->gru_wih, c->gru_whh, c->gru_bih, c->gru_bhh, c->h_state, c->h_masked, c->gru_gi, c->gru_gh, c->d_done, c->gru_x, c->gru_dg}; for (float* q : gr) if (q) hipFree(q); }
     hipFree(c->act); hipFree(c->adv_stats); hipFree(c->d_idx); hipFree(c->sumsq);
     if (c->fs_colmax) hipFree(c->fs_colmax); if (c->fs_arg) hipFree(c->fs_arg);
@@ -904,7 +914,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     } else if (c->H <= 256 && c->A + 1 <= 16 && !tl_ws) {        // one launch (+ its slab sum) for the heads' three gradients (misc.hip: heads_bwd_kernel)
         ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * (c->A + 1) + 2.0 * n * c->H + (double)c->H * (c->A + 1)), 4.0 * n * c->H * (c->A + 1));
         launch_heads_bwd(c->dY, c->feat, c->params + c->wh_off, impala ? 1 : 0, c->dfeat, c->grads + c->wh_off, c->grads + c->bh_off, c->gemm_ws,
-                         n, c->H, c->A + 1, CUR(c));
+                         n, c->H, c->A + 1, CUR(c), !(c->side.armed && !tl_stream));      // (side stream armed: it also sums the slabs)
     } else {
         linear_wgrad(c, c->dY, c->feat, 0, c->grads + c->wh_off, c->grads + c->bh_off, n, c->H, c->A + 1);
         linear_dgrad(c, c->dY, c->params + c->wh_off, impala ? c->feat : nullptr, c->dfeat, n, c->H, c->A + 1);
@@ -923,7 +933,29 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         return;
     }
     const bool fc16 = c->bf && n >= 1024;
-    if (fc16) {
+    bool side_forked = false;
+    if (fc16 && c->side.armed && !tl_stream) {
+        // fork: the side stream takes the logged statistics and embedder.fc's weight / bias gradients (mi_ctx::side_stream); this stream
+        // goes straight on to the data gradient.  Every buffer the side work touches (block-3 output, feat, dfeat, loss partial sums,
+        // the split-K / column-sum / metric workspaces, the fc + head slices of grads) is next written after the join below.
+        fc_refresh(c);
+        const mi_ctx::SideJob& j = c->side;
+        // the first env group's stream when there is one (idle during an update, joined by JOIN(); one hardware queue less in use), else an own stream
+        hipStream_t ss = (c->n_groups > 0 && c->gs[0]) ? c->gs[0] : c->side_stream;
+        if (!ss) { hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking); ss = c->side_stream; }
+        hipEventRecord(c->ev_side_fork, c->stream);
+        hipStreamWaitEvent(ss, c->ev_side_fork, 0);
+        tl_stream = ss;
+        launch_heads_bwd_reduce(c->gemm_ws, c->grads + c->wh_off, c->grads + c->bh_off, n, c->H, c->A + 1, ss);      // (before fc_tn reuses the slabs)
+        launch_fs_metric_seg(c->blk[2].P2, c->bf, j.st, 2048, c->fs_scratch, c->fs_parts, ss);
+        launch_loss_finalize_seg(j.a, j.st, 3, j.ring, c->fs_parts, 2048, j.fsr, j.log, ss);
+        launch_fc_tn(c->dfeat, (const unsigned short*)c->blk[2].P2, c->grads + c->fc.w_off, c->gemm_ws, (size_t)8 << 20, 256, 2048, n, ss);
+        launch_colsum_acc(c->dfeat, n, 256, 256, c->grads + c->fc.b_off, c->col_ws, ss);
+        tl_stream = nullptr;
+        hipEventRecord(c->ev_side_join, ss);
+        c->side.armed = false;
+        side_forked = true;
+    } else if (fc16) {
         fc_refresh(c);
         { ProfScope ps(c, PC_GEMM, n, 2.0 * n * 2048 + 4.0 * n * 256 + 4.0 * 2048 * 256, 2.0 * n * 2048 * 256);
           launch_fc_tn(c->dfeat, (const unsigned short*)c->blk[2].P2, c->grads + c->fc.w_off, c->gemm_ws, (size_t)8 << 20, 256, 2048, n, CUR(c)); }
@@ -1037,6 +1069,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             conv_dgrad(c, L[0], c->GC, nullptr, nullptr, Gout, n);
         }
     }
+    if (side_forked) hipStreamWaitEvent(c->stream, c->ev_side_join, 0);          // join: statistics + fc gradients are in place behind this point
     conv_wgrad_reduce_all(c, n);
     issue_grad_allreduce(c, 0, c->fc.w_off, true);                                 // region B: the conv layers' gradients
 }
@@ -1528,10 +1561,18 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
         float* ring = c->stats_ring + (size_t)c->log_count * 32;
         float* fsr = c->fs_ring + c->log_count;
         a.stats = ring;                                  // (x-entropy gradient, mode 0, n_seg == 1: the batch-mean action distribution)
+        // single rank, no batch-level loss terms, bf16 IMPALA at update size: metric + records leave the critical path (net_backward forks)
+        const bool side = c->side_on && impala && c->bf && n >= 1024 && !batch_terms && c->multirank == 0 && !c->ar_armed && !c->comm && !c->bwd_from_dfeat &&
+                          c->H <= 256 && c->A + 1 <= 16;
+        if (side) {
+            launch_loss_fwd_seg(a, st, true, c->stream);
+            c->side = mi_ctx::SideJob{true, a, st, ring, fsr, c->loss_log + (size_t)c->log_count * 8};
+        } else {
         if (impala) launch_fs_metric_seg(c->blk[2].P2, c->bf, st, 2048, c->fs_scratch, c->fs_parts, c->stream);
         launch_loss_fwd_seg(a, st, !batch_terms, c->stream);
         launch_loss_finalize_seg(a, st, c->multirank == 2 ? 1 : 3, ring, impala ? c->fs_parts : nullptr, 2048, fsr,
                                  c->multirank == 2 ? nullptr : c->loss_log + (size_t)c->log_count * 8, c->stream);
+        }
         c->ring_args = a;
         c->log_count += n_seg;
         if (batch_terms) launch_loss_bwd(a, c->stream);
@@ -1949,7 +1990,7 @@ int mi_op_resblock(mi_ctx* c, int32_t mode, int32_t ch, int32_t hw, int32_t n, c
 }
 
 // bit 0: run rollout-sized bf16 inference passes on the separate block-2 / block-3 kernels instead of the fused launch (parity A/B)
-int mi_debug_flags(mi_ctx* c, int32_t flags) { ARG(c, "null"); JOIN(c); c->rollout_tail = !(flags & 1); c->no_pull = (flags & 4) != 0; return 0; }
+int mi_debug_flags(mi_ctx* c, int32_t flags) { ARG(c, "null"); JOIN(c); c->rollout_tail = !(flags & 1); c->no_pull = (flags & 4) != 0; c->side_on = !(flags & 16); return 0; }
 
 // Philox4x32-10 known-answer hook: n x {c0,c1,c2,c3,k0,k1} in, n x 4 output words and the n uniforms the sampler would draw
 // for (seed = k0 | k1 << 32, counter = c0 | c1 << 32) out.

@@ -530,12 +530,17 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
     if (k < O) sl[(long long)O * H + k] = gb;
 }
 // gW[O][H] += dY^T feat ; gb[O] += colsum(dY) ; dfeat = (dY W) * (feat > 0 if relu_mask).  ws: >= 512 * (O*H + O) floats.
-void launch_heads_bwd(const float* dY, const float* feat, const float* Wh, int relu_mask, float* dfeat, float* gW, float* gb, float* ws,
-                      int n, int H, int O, hipStream_t st) {
+static int heads_bwd_grid(int n) { const int g = (n + 15) / 16; return g > 512 ? 512 : g; }   // 16 rows per workgroup at the training sizes: two steps of 8 rows, two workgroups per CU
+// the slab sum of launch_heads_bwd(..., with_reduce = false), on a stream of the caller's choice (nothing but the optimizer needs gW / gb)
+void launch_heads_bwd_reduce(const float* ws, float* gW, float* gb, int n, int H, int O, hipStream_t st) {
     if (n <= 0) return;
-    int grid = (n + 15) / 16; grid = grid > 512 ? 512 : grid;          // 16 rows per workgroup at the training sizes: two steps of 8 rows, two workgroups per CU
-    hipLaunchKernelGGL(heads_bwd_kernel, dim3(grid), dim3(256), 0, st, dY, feat, Wh, relu_mask, dfeat, ws, n, H, O);
-    launch_reduce_slabs(ws, grid, O * H + O, gW, O * H, gb, O, st);
+    launch_reduce_slabs(ws, heads_bwd_grid(n), O * H + O, gW, O * H, gb, O, st);
+}
+void launch_heads_bwd(const float* dY, const float* feat, const float* Wh, int relu_mask, float* dfeat, float* gW, float* gb, float* ws,
+                      int n, int H, int O, hipStream_t st, bool with_reduce) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3(heads_bwd_grid(n)), dim3(256), 0, st, dY, feat, Wh, relu_mask, dfeat, ws, n, H, O);
+    if (with_reduce) launch_heads_bwd_reduce(ws, gW, gb, n, H, O, st);
 }
 
 __global__ void gather_rows_kernel(const float* src, const int32_t* idx, long long base, float* dst, int n, int d) {
