@@ -746,17 +746,17 @@ static void issue_grad_allreduce(mi_ctx* c, int64_t off, int64_t n, bool last) {
     if (last) { hipEventRecord(c->ev_ar_done, c->comm_stream); c->ar_armed = false; c->ar_issued = true; c->ar_inflight = true; }
 }
 
-static void conv_wgrad_reduce_all(mi_ctx* c, int n) {
+static void conv_wgrad_reduce_all(mi_ctx* c, int n, int first = 0) {          // first: entries [0, first) are summed already (net_backward's second fork)
     if (c->slab_desc_n <= 0) return;
     int max_len = 0; double bytes = 0;
-    for (int k = 0; k < c->slab_desc_n; ++k) { max_len = std::max(max_len, c->h_slab_desc[k].slab_len); bytes += 4.0 * c->h_slab_desc[k].nslab * c->h_slab_desc[k].slab_len; }
+    for (int k = first; k < c->slab_desc_n; ++k) { max_len = std::max(max_len, c->h_slab_desc[k].slab_len); bytes += 4.0 * c->h_slab_desc[k].nslab * c->h_slab_desc[k].slab_len; }
     // the descriptor table only depends on the batch size: re-uploaded when it changes (pageable source copied at call time)
     if (c->slab_desc_cached_n != n) {
         hipMemcpyAsync(c->d_slab_desc, c->h_slab_desc, sizeof(SlabDesc) * c->slab_desc_n, hipMemcpyHostToDevice, CUR(c));
         c->slab_desc_cached_n = n;
     }
     { ProfScope ps(c, PC_SLAB_REDUCE, n, bytes, 0.0);
-      launch_reduce_all_slabs(c->slabs, c->grads, c->d_slab_desc, c->slab_desc_n, max_len, CUR(c)); }
+      launch_reduce_all_slabs(c->slabs, c->grads, c->d_slab_desc + first, c->slab_desc_n - first, max_len, CUR(c)); }
     c->slab_desc_n = 0;
 }
 
@@ -934,6 +934,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     }
     const bool fc16 = c->bf && n >= 1024;
     bool side_forked = false;
+    int slabs_done = 0;          // leading entries of the slab table already summed on the side stream
     if (fc16 && c->side.armed && !tl_stream) {
         // fork: the side stream takes the logged statistics and embedder.fc's weight / bias gradients (mi_ctx::side_stream); this stream
         // goes straight on to the data gradient.  Every buffer the side work touches (block-3 output, feat, dfeat, loss partial sums,
@@ -1041,7 +1042,26 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         conv_dgrad(c, L[1], Ga, k.P0, Gb, Gout, n);
         }
         // max pool, then the block's first conv
-        if (b == 0 && c->bf) { c->sal_src = Gout; conv_wgrad(c, L[0], nullptr, &src, 0, Gout, n, k.PI); break; }     // pool backward fused into the staging
+        if (b == 0 && c->bf) {                 // pool backward fused into the staging
+            c->sal_src = Gout;
+            // second fork: block1.conv's weight gradient is the last kernel of the pass and nothing but its own slabs depends on it, so the
+            // slab sums of the 14 layers before it run beside it (the table on the device is the cached one of this batch size: its last
+            // entry is block1.conv's) and only that last entry is summed behind it
+            if (c->side_on && !tl_stream && n >= 1024 && c->slab_desc_cached_n == n && c->slab_desc_n >= 1) {
+                hipStream_t ss = (c->n_groups > 0 && c->gs[0]) ? c->gs[0] : c->side_stream;
+                if (!ss) { hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking); ss = c->side_stream; }
+                int max_len = 0;
+                for (int q = 0; q < c->slab_desc_n; ++q) max_len = std::max(max_len, c->h_slab_desc[q].slab_len);
+                hipEventRecord(c->ev_side_fork, c->stream);
+                hipStreamWaitEvent(ss, c->ev_side_fork, 0);
+                launch_reduce_all_slabs(c->slabs, c->grads, c->d_slab_desc, c->slab_desc_n, max_len, ss);
+                hipEventRecord(c->ev_side_join, ss);
+                side_forked = true;
+                slabs_done = c->slab_desc_n;
+            }
+            conv_wgrad(c, L[0], nullptr, &src, 0, Gout, n, k.PI);
+            break;
+        }
         if (c->bf) {            // blocks 2, 3: both consumers of the conv-output gradient rebuild it from (pooled gradient, arg-max)
             const int fgrid = conv_bwd_fused_grid(L[0].shape, n);
             if (fgrid > 0) {        // block2.conv: data AND weight gradient in one launch (the max-pool backward gather runs once)
@@ -1069,8 +1089,8 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             conv_dgrad(c, L[0], c->GC, nullptr, nullptr, Gout, n);
         }
     }
-    if (side_forked) hipStreamWaitEvent(c->stream, c->ev_side_join, 0);          // join: statistics + fc gradients are in place behind this point
-    conv_wgrad_reduce_all(c, n);
+    if (side_forked) hipStreamWaitEvent(c->stream, c->ev_side_join, 0);          // join: statistics, fc gradients (and the first slab sums) are in place behind this point
+    conv_wgrad_reduce_all(c, n, slabs_done);
     issue_grad_allreduce(c, 0, c->fc.w_off, true);                                 // region B: the conv layers' gradients
 }
 
