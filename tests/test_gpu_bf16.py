@@ -449,12 +449,15 @@ def test_fc_bf16_matrix_core_path_matches_small_batch_path(T, B):
         assert rel < 1e-1, (k, rel)          # deepest layer measured 3.5e-2: bf16 rounding of d(feat) + of every dgrad output below it
 
 
-def test_side_stream_minibatch_equals_the_single_stream_pass():
+@pytest.mark.parametrize("deferred", [False, True])
+def test_side_stream_minibatch_equals_the_single_stream_pass(deferred):
     """Update-sized bf16 minibatches without batch-level loss terms fork a side stream behind heads_bwd: the feature-sparsity metric,
     the loss records and embedder.fc's weight / bias gradients run beside the rest of the backward pass and are joined in front of the
     slab sums (engine.hip net_backward).  Same kernels on the same data in the same per-buffer order: loss records, gradients and the
     parameters after three optimizer steps (two of them with accumulated half-minibatches: two forks before one optimizer step) are
-    BIT-identical to the single-stream pass (mi_debug_flags bit 4)."""
+    BIT-identical to the single-stream pass (mi_debug_flags bit 4).  deferred: the multi-rank schedule without batch-level loss terms
+    (mi_set_multirank mode 2: partial sums into the statistics ring, records derived once per optimize() by mi_loss_log_finalize) --
+    what every rank of an 8-GPU run executes; here on one rank, where the cross-rank sum is the identity."""
     from mi355 import engine as M, layout
     from mi355.engine import Engine
     T, E, A, B = 32, 64, 15, 2048
@@ -466,6 +469,8 @@ def test_side_stream_minibatch_equals_the_single_stream_pass():
         eng = Engine("impala", T, E, A, B, precision="bf16")
         eng.set_params(flat)
         eng.debug_flags(flags)
+        if deferred:
+            eng.set_multirank(2)
         for t in range(T + 1):
             eng.put_obs(t, frames[t]); eng.sync()
         r2 = np.random.default_rng(4)
@@ -482,6 +487,8 @@ def test_side_stream_minibatch_equals_the_single_stream_pass():
         for k in range(2):
             eng.minibatch(idx[:B // 2], B, eng.hparams()); eng.minibatch(idx[B // 2:], B, eng.hparams())
             eng.optimizer_step(5e-4, 0.5, 1)
+        if deferred:
+            eng.loss_log_finalize()
         out.append((g1, np.array(eng.loss_log()), eng.get_params().copy()))
         eng.close()
     assert np.abs(out[0][0]).max() > 0 and len(out[0][1]) == 5

@@ -172,7 +172,7 @@ struct mi_ctx {
     // Fork after heads_bwd, join in front of the slab sums.
     hipStream_t side_stream; hipEvent_t ev_side_fork, ev_side_join;
     bool side_on;               // mi_debug_flags bit 4 clears it (A/B tests)
-    struct SideJob { bool armed; LossArgs a; SegTab st; float* ring; float* fsr; float* log; } side;
+    struct SideJob { bool armed; LossArgs a; SegTab st; int mode; float* ring; float* fsr; float* log; } side;
     bool rollout_tail;          // bf16 inference passes of <= 256 samples run blocks 2 + 3 as one launch (mi_debug_flags bit 0 clears it: A/B tests)
     float *fs_colmax, fs_grad_coef; int *fs_arg, fs_G;      // feature-sparsity gradient (fs_coef != 0): column maxima / first arg-max rows of the minibatch
     // ... on more than one rank (multirank mode 1): per-column candidates for the max-all-reduce (MI_PTR_FS_KEYS), this rank's own copy, and
@@ -949,7 +949,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         tl_stream = ss;
         launch_heads_bwd_reduce(c->gemm_ws, c->grads + c->wh_off, c->grads + c->bh_off, n, c->H, c->A + 1, ss);      // (before fc_tn reuses the slabs)
         launch_fs_metric_seg(c->blk[2].P2, c->bf, j.st, 2048, c->fs_scratch, c->fs_parts, ss);
-        launch_loss_finalize_seg(j.a, j.st, 3, j.ring, c->fs_parts, 2048, j.fsr, j.log, ss);
+        launch_loss_finalize_seg(j.a, j.st, j.mode, j.ring, c->fs_parts, 2048, j.fsr, j.log, ss);
         launch_fc_tn(c->dfeat, (const unsigned short*)c->blk[2].P2, c->grads + c->fc.w_off, c->gemm_ws, (size_t)8 << 20, 256, 2048, n, ss);
         launch_colsum_acc(c->dfeat, n, 256, 256, c->grads + c->fc.b_off, c->col_ws, ss);
         tl_stream = nullptr;
@@ -1581,12 +1581,13 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
         float* ring = c->stats_ring + (size_t)c->log_count * 32;
         float* fsr = c->fs_ring + c->log_count;
         a.stats = ring;                                  // (x-entropy gradient, mode 0, n_seg == 1: the batch-mean action distribution)
-        // single rank, no batch-level loss terms, bf16 IMPALA at update size: metric + records leave the critical path (net_backward forks)
-        const bool side = c->side_on && impala && c->bf && n >= 1024 && !batch_terms && c->multirank == 0 && !c->ar_armed && !c->comm && !c->bwd_from_dfeat &&
+        // no batch-level loss terms, bf16 IMPALA at update size, gradients exchanged (if at all) behind the pass: metric + records leave the
+        // critical path (net_backward forks); the in-library armed exchange hands region A over in the middle of the pass and keeps the old order
+        const bool side = c->side_on && impala && c->bf && n >= 1024 && !batch_terms && !c->ar_armed && !c->comm && !c->bwd_from_dfeat &&
                           c->H <= 256 && c->A + 1 <= 16;
         if (side) {
             launch_loss_fwd_seg(a, st, true, c->stream);
-            c->side = mi_ctx::SideJob{true, a, st, ring, fsr, c->loss_log + (size_t)c->log_count * 8};
+            c->side = mi_ctx::SideJob{true, a, st, c->multirank == 2 ? 1 : 3, ring, fsr, c->multirank == 2 ? nullptr : c->loss_log + (size_t)c->log_count * 8};
         } else {
         if (impala) launch_fs_metric_seg(c->blk[2].P2, c->bf, st, 2048, c->fs_scratch, c->fs_parts, c->stream);
         launch_loss_fwd_seg(a, st, !batch_terms, c->stream);
