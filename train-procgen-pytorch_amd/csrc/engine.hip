@@ -153,7 +153,7 @@ struct mi_ctx {
     // pinned host staging
     // index staging ring: a slot is rewritten only after the H2D copy that read it has completed
     static constexpr int IDX_RING = 32;
-    int32_t* h_idx_ring[IDX_RING]; hipEvent_t idx_ev[IDX_RING]; bool idx_used[IDX_RING]; int idx_next;
+    int32_t* h_idx_ring[IDX_RING]; hipEvent_t idx_ev[IDX_RING]; bool idx_used[IDX_RING]; int idx_next, idx_ev_deferred;
     float* h_f; int32_t* h_i; size_t h_f_floats;
     int multirank;
     LossArgs pending; int pending_n;
@@ -419,7 +419,7 @@ int mi_create(const mi_config* cfg, mi_ctx** out) {
         HIPC(hipEventCreateWithFlags(&c->idx_ev[k], hipEventDisableTiming));
         c->idx_used[k] = false;
     }
-    c->idx_next = 0;
+    c->idx_next = 0; c->idx_ev_deferred = -1;
     c->h_f_floats = (size_t)4 * (E > 64 ? E : 64);
     HIPC(hipHostMalloc((void**)&c->h_f, c->h_f_floats * sizeof(float)));
     HIPC(hipHostMalloc((void**)&c->h_i, (size_t)E * sizeof(int32_t)));
@@ -946,6 +946,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         if (!ss) { hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking); ss = c->side_stream; }
         hipEventRecord(c->ev_side_fork, c->stream);
         hipStreamWaitEvent(ss, c->ev_side_fork, 0);
+        if (c->idx_ev_deferred >= 0) { hipEventRecord(c->idx_ev[c->idx_ev_deferred], ss); c->idx_ev_deferred = -1; }      // (minibatch_impl: the index slot's "read" marker)
         tl_stream = ss;
         launch_heads_bwd_reduce(c->gemm_ws, c->grads + c->wh_off, c->grads + c->bh_off, n, c->H, c->A + 1, ss);      // (before fc_tn reuses the slabs)
         launch_fs_metric_seg(c->blk[2].P2, c->bf, j.st, 2048, c->fs_scratch, c->fs_parts, ss);
@@ -1534,6 +1535,10 @@ static InputSrc minibatch_src(mi_ctx* c) {
 // statistics are taken and logged per segment.  n_seg > 1 is gradient accumulation done in one launch set (agents/ppo.py:170-177
 // sums the gradients of the accumulated minibatches before the optimizer step, so only the fp32 summation order changes); it
 // needs a loss without batch-level terms (x_entropy_coef == 0, fs_coef == 0).
+static bool side_eligible(const mi_ctx* c, int n, bool batch_terms) {
+    return c->side_on && c->cfg.arch == MI_ARCH_IMPALA && c->bf && n >= 1024 && !batch_terms && !c->ar_armed && !c->comm && !c->bwd_from_dfeat &&
+           c->H <= 256 && c->A + 1 <= 16;
+}
 static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_t* seg_n, int32_t n_seg, int32_t n_global, const mi_hparams* hp) {
     ARG(c && hp, "null"); JOIN(c); ARG(n >= 0 && n <= c->NB, "n_idx must be in [0, max_batch]"); ARG(n_global >= 1, "n_global");
     ARG(n == 0 || idx, "idx"); ARG(n_seg >= 1 && n_seg <= MI_MAX_SEG && seg_n, "1 .. 16 segments");
@@ -1554,7 +1559,11 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
         int32_t* h = c->h_idx_ring[slot];
         for (int k = 0; k < n; ++k) h[k] = (int32_t)idx[k];
         launch_pull_i32(h, c->d_idx, n, c->stream);              // (not hipMemcpyAsync: see pull_i32_kernel)
-        HIPC(hipEventRecord(c->idx_ev[slot], c->stream));
+        // "slot read" marker: an event record between the pull and the first conv kernel is a ~5 us bubble on the main stream (kernel
+        // traces: 5-7 us between pull_i32 and repack_all); when this pass forks the side stream, the marker is recorded THERE, behind
+        // the fork (which is behind the pull in main-stream order)
+        if (side_eligible(c, n, batch_terms) && c->multirank != 1) c->idx_ev_deferred = slot;
+        else HIPC(hipEventRecord(c->idx_ev[slot], c->stream));
         c->idx_used[slot] = true;
     }
     InputSrc src = minibatch_src(c);
@@ -1583,8 +1592,7 @@ static int minibatch_impl(mi_ctx* c, const int64_t* idx, int32_t n, const int32_
         a.stats = ring;                                  // (x-entropy gradient, mode 0, n_seg == 1: the batch-mean action distribution)
         // no batch-level loss terms, bf16 IMPALA at update size, gradients exchanged (if at all) behind the pass: metric + records leave the
         // critical path (net_backward forks); the in-library armed exchange hands region A over in the middle of the pass and keeps the old order
-        const bool side = c->side_on && impala && c->bf && n >= 1024 && !batch_terms && !c->ar_armed && !c->comm && !c->bwd_from_dfeat &&
-                          c->H <= 256 && c->A + 1 <= 16;
+        const bool side = side_eligible(c, n, batch_terms);
         if (side) {
             launch_loss_fwd_seg(a, st, true, c->stream);
             c->side = mi_ctx::SideJob{true, a, st, c->multirank == 2 ? 1 : 3, ring, fsr, c->multirank == 2 ? nullptr : c->loss_log + (size_t)c->log_count * 8};
