@@ -148,7 +148,7 @@ void launch_maxpool_bwd(const float* dout, const uint8_t* arg, float* din, int n
 void launch_maxpool_fwd_bf16(const void* in, void* out, uint8_t* arg, int n, int hw, int c, hipStream_t st);
 void launch_maxpool_bwd_bf16(const void* dout, const uint8_t* arg, void* din, int n, int hw, int c, hipStream_t st);
 void launch_heads_bwd(const float* dY, const float* feat, const float* Wh, int relu_mask, float* dfeat, float* gW, float* gb, float* ws /* >= 256 * (O*H + O) floats */,
-                      int n, int H, int O, hipStream_t st, bool with_reduce = true);
+                      int n, int H, int O, hipStream_t st, bool with_reduce = true, hipEvent_t done_ev = nullptr);
 void launch_heads_bwd_reduce(const float* ws, float* gW, float* gb, int n, int H, int O, hipStream_t st);      // heads' data + weight + bias gradient in one launch (+ the slab sum); H <= 256, O <= 16
 void launch_reduce_slabs(const float* partial, int nslab, int slab_len, float* dst_w, int n_w, float* dst_b, int n_b,
                          hipStream_t st);

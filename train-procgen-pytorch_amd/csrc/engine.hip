@@ -906,6 +906,9 @@ static void net_forward(mi_ctx* c, const InputSrc& src, int n, bool recurrent = 
     if (with_heads) net_heads(c, n, soff);
 }
 
+#ifndef SIDE_EXT_EVENT
+#define SIDE_EXT_EVENT 1
+#endif
 // backward from dY (n x (A+1)); gradients accumulate into c->grads
 static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     const bool impala = c->cfg.arch == MI_ARCH_IMPALA;
@@ -914,7 +917,8 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     } else if (c->H <= 256 && c->A + 1 <= 16 && !tl_ws) {        // one launch (+ its slab sum) for the heads' three gradients (misc.hip: heads_bwd_kernel)
         ProfScope ps(c, PC_GEMM, n, 4.0 * ((double)n * (c->A + 1) + 2.0 * n * c->H + (double)c->H * (c->A + 1)), 4.0 * n * c->H * (c->A + 1));
         launch_heads_bwd(c->dY, c->feat, c->params + c->wh_off, impala ? 1 : 0, c->dfeat, c->grads + c->wh_off, c->grads + c->bh_off, c->gemm_ws,
-                         n, c->H, c->A + 1, CUR(c), !(c->side.armed && !tl_stream));      // (side stream armed: it also sums the slabs)
+                         n, c->H, c->A + 1, CUR(c), !(c->side.armed && !tl_stream),      // (side stream armed: it also sums the slabs ...
+                         (c->side.armed && !tl_stream && SIDE_EXT_EVENT) ? c->ev_side_fork : nullptr);      //  ... and forks on this launch's completion)
     } else {
         linear_wgrad(c, c->dY, c->feat, 0, c->grads + c->wh_off, c->grads + c->bh_off, n, c->H, c->A + 1);
         linear_dgrad(c, c->dY, c->params + c->wh_off, impala ? c->feat : nullptr, c->dfeat, n, c->H, c->A + 1);
@@ -944,7 +948,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
         // the first env group's stream when there is one (idle during an update, joined by JOIN(); one hardware queue less in use), else an own stream
         hipStream_t ss = (c->n_groups > 0 && c->gs[0]) ? c->gs[0] : c->side_stream;
         if (!ss) { hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking); ss = c->side_stream; }
-        hipEventRecord(c->ev_side_fork, c->stream);
+        if (!SIDE_EXT_EVENT) hipEventRecord(c->ev_side_fork, c->stream);          // (else: heads_bwd_kernel's own completion, launch_heads_bwd above)
         hipStreamWaitEvent(ss, c->ev_side_fork, 0);
         if (c->idx_ev_deferred >= 0) { hipEventRecord(c->idx_ev[c->idx_ev_deferred], ss); c->idx_ev_deferred = -1; }      // (minibatch_impl: the index slot's "read" marker)
         tl_stream = ss;

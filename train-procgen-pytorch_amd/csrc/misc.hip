@@ -2,6 +2,7 @@
 // by the linear layers.  gfx950 only (64-lane waves).  Every reduction has a fixed summation
 // order: results are bitwise reproducible run to run (no float atomics anywhere).
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
 
@@ -537,8 +538,12 @@ void launch_heads_bwd_reduce(const float* ws, float* gW, float* gb, int n, int H
     launch_reduce_slabs(ws, heads_bwd_grid(n), O * H + O, gW, O * H, gb, O, st);
 }
 void launch_heads_bwd(const float* dY, const float* feat, const float* Wh, int relu_mask, float* dfeat, float* gW, float* gb, float* ws,
-                      int n, int H, int O, hipStream_t st, bool with_reduce) {
+                      int n, int H, int O, hipStream_t st, bool with_reduce, hipEvent_t done_ev) {
     if (n <= 0) return;
+    // done_ev: completion of THIS launch as an event (hipExtLaunchKernelGGL: the dispatch packet's own completion signal) -- a separate
+    // hipEventRecord behind the kernel is one more packet on the queue and a 7-9 us bubble in front of the next kernel
+    if (done_ev) hipExtLaunchKernelGGL(heads_bwd_kernel, dim3(heads_bwd_grid(n)), dim3(256), 0, st, nullptr, done_ev, 0, dY, feat, Wh, relu_mask, dfeat, ws, n, H, O);
+    else
     hipLaunchKernelGGL(heads_bwd_kernel, dim3(heads_bwd_grid(n)), dim3(256), 0, st, dY, feat, Wh, relu_mask, dfeat, ws, n, H, O);
     if (with_reduce) launch_heads_bwd_reduce(ws, gW, gb, n, H, O, st);
 }
