@@ -241,7 +241,8 @@ void launch_resblock_bf16(ConvShape s, const void* x, const float* b1, const flo
                           const unsigned short* bank1, const unsigned short* bank2, hipStream_t st);
 int  resblock_bwd_full_grid(int n);
 void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
-                                   const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st);
+                                   const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st, hipEvent_t done_ev = nullptr /* set: recorded at this launch's completion; only the default (16d) kernel honours it, the caller checks launch_resblock_bwd_full_event_ok() */);
+bool launch_resblock_bwd_full_event_ok();
 int  resblock_bwd_full32_grid(ConvShape s, int n);
 void launch_resblock_bwd_full32_bf16(ConvShape s, const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
                                      const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st);

@@ -939,6 +939,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
     const bool fc16 = c->bf && n >= 1024;
     bool side_forked = false;
     int slabs_done = 0;          // leading entries of the slab table already summed on the side stream
+    bool fork2_on_launch = false;
     if (fc16 && c->side.armed && !tl_stream) {
         // fork: the side stream takes the logged statistics and embedder.fc's weight / bias gradients (mi_ctx::side_stream); this stream
         // goes straight on to the data gradient.  Every buffer the side work touches (block-3 output, feat, dfeat, loss partial sums,
@@ -1012,18 +1013,20 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
             if (L[1].shape == CS_16_16_32) {
                 // 16 channels @32x32: data gradients AND both weight gradients in one launch (resblock_bwd_full_bf16_kernel);
                 // the gradient of conv1's output never reaches HBM
-                auto rb_full = [&](const ConvLayer& l1, const ConvLayer& l2, const float* dy, const float* a_fwd, const float* x_fwd, float* dx) {
+                auto rb_full = [&](const ConvLayer& l1, const ConvLayer& l2, const float* dy, const float* a_fwd, const float* x_fwd, float* dx, hipEvent_t done_ev = nullptr) {
                     const int grid = resblock_bwd_full_grid(n);
                     const int i1 = (int)(&l1 - c->convs.data()), i2 = (int)(&l2 - c->convs.data());
                     { ProfScope ps(c, PC_RESBLOCK_BWD + (int)l1.shape, n, px * ch * 2.0 * 7, 4.0 * px * 18.0 * ch * ch);      // 8(d): 2 convs x 3p + skip-gradient p = 7p (the kernel itself moves 4p)
                       launch_resblock_bwd_full_bf16(dy, a_fwd, x_fwd, dx, nullptr, n, c->banks + l2.bank_d, c->banks + l1.bank_d,
-                                                    c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], CUR(c)); }
+                                                    c->slabs + c->slab_off[i2], c->slabs + c->slab_off[i1], CUR(c), done_ev); }
                     const int wlen = l1.cout * 9 * l1.cin;
                     c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[i2], (long long)l2.w_off, (long long)l2.b_off, grid, wlen + l2.cout, wlen};
                     c->h_slab_desc[c->slab_desc_n++] = SlabDesc{c->slab_off[i1], (long long)l1.w_off, (long long)l1.b_off, grid, wlen + l1.cout, wlen};
                 };
                 rb_full(L[3], L[4], Gout, k.A2, k.P1, Gb);      // res2: P2 = conv2(relu(A2)) + P1 ; A2 = conv1(relu(P1))
-                rb_full(L[1], L[2], Gb, k.A1, k.P0, Gout);      // res1: P1 = conv2(relu(A1)) + P0 ; A1 = conv1(relu(P0))
+                // (block 1's res1 is the last launch in front of the second fork: the fork event is this launch's own completion)
+                fork2_on_launch = b == 0 && SIDE_EXT_EVENT && c->side_on && !tl_stream && n >= 1024 && c->slab_desc_cached_n == n && launch_resblock_bwd_full_event_ok();
+                rb_full(L[1], L[2], Gb, k.A1, k.P0, Gout, fork2_on_launch ? c->ev_side_fork : nullptr);      // res1: P1 = conv2(relu(A1)) + P0 ; A1 = conv1(relu(P0))
             } else {
             // res2: P2 = conv2(relu(A2)) + P1 ; A2 = conv1(relu(P1))
             rb_bwd(L[3], L[4], Gout, k.A2, k.P1, Ga, Gb);
@@ -1057,7 +1060,7 @@ static void net_backward(mi_ctx* c, const InputSrc& src, int n) {
                 if (!ss) { hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking); ss = c->side_stream; }
                 int max_len = 0;
                 for (int q = 0; q < c->slab_desc_n; ++q) max_len = std::max(max_len, c->h_slab_desc[q].slab_len);
-                hipEventRecord(c->ev_side_fork, c->stream);
+                if (!fork2_on_launch) hipEventRecord(c->ev_side_fork, c->stream);
                 hipStreamWaitEvent(ss, c->ev_side_fork, 0);
                 launch_reduce_all_slabs(c->slabs, c->grads, c->d_slab_desc, c->slab_desc_n, max_len, ss);
                 hipEventRecord(c->ev_side_join, ss);

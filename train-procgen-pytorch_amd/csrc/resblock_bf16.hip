@@ -13,6 +13,7 @@
 // MFMA operand order as in conv_bf16.hip: filter rows = A, pixels = B, so a lane owns 4 consecutive channels of a
 // pixel and every global / LDS access of the epilogues is an 8-byte word.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <mutex>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -1645,8 +1646,9 @@ int resblock_bwd_full_grid(int n) {
     return w > 256 * bpc ? 256 * bpc : w;
 }
 // 16-channel residual blocks @32x32 only (CS_16_16_32).  slab2 / slab1: [grid][2320] floats each (grid = resblock_bwd_full_grid(n)).
+bool launch_resblock_bwd_full_event_ok() { return RBFULL16_SPECIALISED == 2; }
 void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void* x_fwd, void* dx_out, void* da_out, int n,
-                                   const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st) {
+                                   const unsigned short* bank2_t, const unsigned short* bank1_t, float* slab2, float* slab1, hipStream_t st, hipEvent_t done_ev) {
     static std::once_flag attr;          // (launchers run on up to 4 group worker threads)
     std::call_once(attr, [] { hipFuncSetAttribute((const void*)resblock_bwd_full_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbFull::LDS_BYTES); });
     const int grid = resblock_bwd_full_grid(n);
@@ -1665,6 +1667,9 @@ void launch_resblock_bwd_full_bf16(const void* dy, const void* a_fwd, const void
             constexpr size_t LDS_D = RBFULL16D_NBUF * RbFull16S::TILE_BYTES > RbFull16S::RED_BYTES ? RBFULL16D_NBUF * RbFull16S::TILE_BYTES : RbFull16S::RED_BYTES;
             static_assert(LDS_D > 80 * 1024 && LDS_D <= 160 * 1024, "one workgroup per CU");
             std::call_once(attr_d, [] { hipFuncSetAttribute((const void*)resblock_bwd_full16d_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_D); });
+            // done_ev: this launch's completion as an event (the dispatch packet's own signal: no marker packet behind the kernel)
+            if (done_ev) hipExtLaunchKernelGGL(resblock_bwd_full16d_bf16_kernel, dim3(grid), dim3(512), (unsigned)LDS_D, st, nullptr, done_ev, 0, a);
+            else
             hipLaunchKernelGGL(resblock_bwd_full16d_bf16_kernel, dim3(grid), dim3(512), LDS_D, st, a);
             return;
         }
